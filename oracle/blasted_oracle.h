@@ -1,0 +1,111 @@
+/* blasted_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C99 + OpenMP) of the BLASTed preconditioner-apply hot path, used ONLY as
+ * the checker: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
+ * blasted_amd/ may include, link or call this.
+ *
+ * Parity status: PINNED TO TOLERANCE, not bit-exact.  The reference (C++14) cannot be built in this
+ * image: every translation unit on the path includes Eigen (include/blasted_config.hpp:9) and
+ * Boost.Align (include/arrayview.hpp:10), neither is installed, and stand-in headers are not allowed.
+ * The restatement is therefore pinned by the reference's own known-answer fixtures and self-checks
+ * (tests/test_oracle_pins.py):
+ *   - SpMV against the shipped products  (tests/mat_ops/CMakeLists.txt:57-94, testbsrmatrix.cpp:46-48)
+ *   - preconditioned BiCGSTAB against the shipped solutions (tests/CMakeLists.txt:34-173,
+ *     tests/testsolve.cpp:107-116)
+ *   - one serial sweep == exact ILU(0): remainder/initial < 5e-16
+ *     (tests/solverops/async_ilu_convergence.cpp:462-490,574-575) and == textbook IKJ ILU(0), which is
+ *     what the reference's `issame` comparison against PETSc's ilu pins (tests/testutils.cpp:66-106)
+ *   - async sweeps converge to the serial result (tests/solverops/CMakeLists.txt:6-111)
+ * The only third-party arithmetic on the path is Eigen's fixed-size product and inverse(); Eigen is an
+ * un-vendored, un-pinned dependency (README.md:13 "Eigen >= 3.3.4").  inverse() is restated here as
+ * adjugate/determinant for n<=4 and Gauss-Jordan with partial pivoting above; the operation order
+ * still differs from Eigen's in the last bits.
+ *
+ * Conventions (include/srmatrixdefs.hpp:98-125): browptr[nbrows+1], bcolind[nnzb] ascending inside a
+ * row, diagind[nbrows] = storage position of the diagonal block, vals[nnzb*bs*bs]; a block is
+ * column-major unless rowmajor!=0; vectors are block-interleaved x[i*bs+c].
+ */
+#ifndef BLASTED_ORACLE_H
+#define BLASTED_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int nbrows;
+	int nnzb;
+	int bs;
+	int rowmajor;
+	const int *browptr;
+	const int *bcolind;
+	const int *diagind;
+	const double *vals;
+} orc_bsr;
+
+/* sweep semantics */
+enum { ORC_GS_SERIAL = 0,    /* in-place, in order: the reference at OMP_NUM_THREADS=1            */
+       ORC_JACOBI_SYNC = 1,  /* double-buffered: deterministic model of one GPU launch per sweep  */
+       ORC_ASYNC_OMP = 2 };  /* the reference's threaded loop nest (omp for dynamic nowait)       */
+
+/* include/async_initialization_decl.hpp:15-34 (same numeric values) */
+enum { ORC_INIT_F_ZERO = 0, ORC_INIT_F_ORIGINAL = 1, ORC_INIT_F_SGS = 2, ORC_INIT_F_NONE = 3 };
+enum { ORC_INIT_A_ZERO = 0, ORC_INIT_A_JACOBI = 1, ORC_INIT_A_NONE = 2 };
+
+int orc_num_threads(void);
+
+/* src/ilu_pattern.cpp:32-163.  count: fills posptr[nnzb+1], returns total pairs.  */
+long orc_ilu_positions_count(const orc_bsr *m, int *posptr);
+void orc_ilu_positions_fill(const orc_bsr *m, const int *posptr, int *lowerp, int *upperp);
+
+/* src/rawsrmatrixutils.cpp:343-350 */
+void orc_scaling_vector(const orc_bsr *m, double *scale);
+
+/* Eigen inverse() stand-in: adjugate/determinant for bs<=4 (Eigen's closed form), Gauss-Jordan with
+ * partial pivoting above (Eigen: PartialPivLU).  returns 0, or 1 if singular. */
+int orc_block_inverse(int bs, int rowmajor, const double *a, double *ainv);
+
+/* src/async_blockilu_factor.cpp:47-149 (bs>1: diagonal blocks inverted in place at the end) and
+ * src/async_ilu_factor.cpp:36-98 (bs==1: diagonal NOT inverted; INIT_F_ZERO falls through to ORIGINAL).
+ * scale: NULL = no scaling, otherwise receives the scaling vector (nbrows*bs) and it is used.
+ * precinfo: NULL or 6 doubles in PrecInfo order (include/preconditioner_diagnostics.hpp:14-43).
+ * returns 0, or -1 for an invalid argument. */
+int orc_ilu0_factorize(const orc_bsr *m, const int *posptr, const int *lowerp, const int *upperp,
+                       int nbuildsweeps, int chunk, int mode, int init_type,
+                       double *iluvals, double *scale, double *precinfo);
+
+/* src/solverops_ilu0.cpp:55-148 (block) and :239-321 (scalar).  returns -1 on invalid init type. */
+int orc_ilu0_apply(const orc_bsr *m, const double *iluvals, const double *scale, double *ytemp,
+                   int napplysweeps, int chunk, int mode, int init_type,
+                   const double *r, double *z);
+
+/* src/solverops_jacobi.cpp:31-48,141-162 and :51-63 */
+int orc_jacobi_compute(const orc_bsr *m, double *dblocks);
+void orc_jacobi_apply(const orc_bsr *m, const double *dblocks, const double *r, double *z);
+
+/* src/solverops_sgs.cpp:47-83 / :149-176.  In ORC_ASYNC_OMP the forward sweeps stay serial (the
+ * reference's orphaned `omp for`, src/kernels/kernels_sgs.hpp:127), the backward ones are threaded. */
+void orc_sgs_apply(const orc_bsr *m, const double *dblocks, double *ytemp,
+                   int napplysweeps, int chunk, int mode, int init_type,
+                   const double *r, double *z);
+
+/* src/solverops_sgs.cpp:85-116 / :178-203 */
+void orc_sgs_relax(const orc_bsr *m, const double *dblocks, int maxits, int chunk, int mode,
+                   const double *b, double *x);
+
+/* src/blas/matvecs.cpp:26-108 */
+void orc_spmv(const orc_bsr *m, const double *x, double *y);
+void orc_gemv3(const orc_bsr *m, double a, const double *x, double b, const double *y, double *z);
+
+/* src/async_blockilu_factor.cpp:256-297, src/async_ilu_factor.cpp:179-217.
+ * iluvals must hold NON-inverted diagonal blocks. */
+double orc_ilu0_nonlinear_res(const orc_bsr *m, const int *posptr, const int *lowerp,
+                              const int *upperp, const double *scale, const double *iluvals);
+
+/* src/matrix_properties.cpp:10-77: out = {lower_avg, lower_min, upper_avg, upper_min} */
+void orc_diag_dominance(const orc_bsr *m_with_factor_vals, double *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,371 @@
+"""Pins the CPU oracle (oracle/blasted_oracle.c) to the reference's own known answers.
+
+The reference cannot be built in this image (Eigen/Boost absent), so the oracle is pinned by every
+known-answer fixture and self-check the reference's tests hold for this path:
+  * SpMV products shipped with the matrices          tests/mat_ops/CMakeLists.txt:57-94
+  * preconditioned BiCGSTAB against shipped solutions tests/CMakeLists.txt:34-173
+  * one serial sweep == exact ILU(0)                  tests/solverops/async_ilu_convergence.cpp:462-490
+  * async sweeps converge to the serial result        tests/solverops/CMakeLists.txt:6-111
+  * serial ILU(0) == textbook IKJ ILU(0)              tests/testutils.cpp:66-106 (`issame` vs PETSc ilu)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from blasted_amd import mtxio, workloads as W
+from krylov import bicgstab
+
+DBL_EPS = np.finfo(np.float64).eps
+
+
+def G(golden, name):
+    return os.path.join(golden, name)
+
+
+# ------------------------------------------------------------------ independent checkers
+
+def brute_ilu_positions(m):
+    """Dictionary-based restatement of the definition (include/ilu_pattern.hpp:30-37): for entry
+    (i,j) all k < min(i,j) with (i,k) and (k,j) stored, ascending k."""
+    bp, bc = m["browptr"], m["bcolind"]
+    where = {}
+    for i in range(m["nbrows"]):
+        for p in range(bp[i], bp[i + 1]):
+            where[(i, int(bc[p]))] = p
+    posptr, lo, up = [0], [], []
+    for i in range(m["nbrows"]):
+        for p in range(bp[i], bp[i + 1]):
+            j = int(bc[p])
+            for q in range(bp[i], bp[i + 1]):
+                k = int(bc[q])
+                if k < min(i, j) and (k, j) in where:
+                    lo.append(q)
+                    up.append(where[(k, j)])
+            posptr.append(len(lo))
+    return np.array(posptr, np.int32), np.array(lo, np.int32), np.array(up, np.int32)
+
+
+def textbook_block_ilu0(m):
+    """IKJ block ILU(0) on the pattern, natural ordering; returns blocks [nnzb,bs,bs] (math layout)
+    with L unit-lower (L_ij = a_ij U_jj^-1 form) and U including NON-inverted diagonal."""
+    bs = m["bs"]
+    a = m["vals"].reshape(-1, bs, bs).copy()
+    if not m["rowmajor"]:
+        a = a.transpose(0, 2, 1).copy()
+    bp, bc, dg = m["browptr"], m["bcolind"], m["diagind"]
+    for i in range(m["nbrows"]):
+        pos = {int(bc[p]): p for p in range(bp[i], bp[i + 1])}
+        for p in range(bp[i], dg[i]):
+            k = int(bc[p])
+            a[p] = a[p] @ np.linalg.inv(a[dg[k]])
+            for q in range(dg[k] + 1, bp[k + 1]):
+                j = int(bc[q])
+                if j in pos:
+                    a[pos[j]] = a[pos[j]] - a[p] @ a[q]
+    return a
+
+
+def factor_blocks(m, iluvals):
+    bs = m["bs"]
+    f = iluvals.reshape(-1, bs, bs)
+    return f if m["rowmajor"] else f.transpose(0, 2, 1)
+
+
+# ------------------------------------------------------------------ G6: SpMV known answers
+
+@pytest.mark.parametrize("bs,rowmajor", [(1, False), (7, True), (7, False)])
+def test_spmv_dk01r(golden, bs, rowmajor):
+    m = mtxio.read_mtx_bsr(G(golden, "DK01R.mtx"), bs, rowmajor)
+    x = mtxio.read_mtx_dense(G(golden, "DK01R_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "DK01R_b.mtx"))
+    y = O.spmv(m, x)
+    assert np.all(np.abs(y - b) < 10 * DBL_EPS)  # tests/mat_ops/testbsrmatrix.cpp:46-48
+
+
+@pytest.mark.parametrize("rowmajor", [False, True])
+def test_spmv_small_block3(golden, rowmajor):
+    m = mtxio.read_mtx_bsr(G(golden, "small_block3_matrix.mtx"), 3, rowmajor)
+    x = mtxio.read_mtx_dense(G(golden, "small_block3_matrix_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "small_block3_matrix_b.mtx"))
+    assert np.all(np.abs(O.spmv(m, x) - b) < 10 * DBL_EPS)
+
+
+def test_spmv_gemv3_2dcyl1(golden):
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4)
+    x = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
+    assert np.linalg.norm(O.spmv(m, x) - b) < 1e-12  # SURVEY: 4.9e-14
+    A = mtxio.bsr_to_scipy(m)
+    yy = W.rhs_vector(x.size)
+    z = O.gemv3(m, -1.5, x, 0.25, yy)
+    ref = -1.5 * (A @ x) + 0.25 * yy
+    assert np.abs(z - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------ G1: ILU positions (bit-exact)
+
+@pytest.mark.parametrize("case", ["2dcyl1", "msc", "poisson9", "random"])
+def test_ilu_positions_bit_exact(golden, case):
+    if case == "2dcyl1":
+        m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4)
+    elif case == "msc":
+        m = mtxio.read_mtx_bsr(G(golden, "msc00726.mtx"), 1)
+    elif case == "poisson9":
+        m = W.poisson3d(9, 1)
+    else:
+        m = W.random_bsr(300, 3, avg_offdiag=6)
+    got = O.ilu_positions(m)
+    want = brute_ilu_positions(m)
+    for g, w in zip(got, want):
+        assert g.dtype == np.int32 and np.array_equal(g, w)
+    if case == "poisson9":
+        # only diagonal entries have pairs on a 7-point grid (src/ilu_pattern.cpp:92-98)
+        cnt = np.diff(got[0])
+        off = np.ones(m["nnzb"], bool)
+        off[m["diagind"]] = False
+        assert np.all(cnt[off] == 0)
+        assert got[1].size == 3 * 7 ** 3 - 3 * 7 ** 2
+
+
+# ------------------------------------------------------------------ G2/G3: serial sweep == exact ILU(0)
+
+def _cases(golden):
+    return {
+        "2dcyl1_bsr4_col": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False),
+        "2dcyl1_bsr4_row": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, True),
+        "2dcyl1_csr": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 1),
+        "msc_csr": lambda: mtxio.read_mtx_bsr(G(golden, "msc00726.mtx"), 1),
+        "poisson16_csr": lambda: W.poisson3d(16, 1),
+        "poisson16_bs4": lambda: W.poisson3d(16, 4),
+        "poisson12_bs5": lambda: W.poisson3d(12, 5),
+        "poisson8_bs8": lambda: W.poisson3d(8, 8),
+    }
+
+
+CASES = ["2dcyl1_bsr4_col", "2dcyl1_bsr4_row", "2dcyl1_csr", "msc_csr", "poisson16_csr",
+         "poisson16_bs4", "poisson12_bs5", "poisson8_bs8"]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("usescale", [False, True])
+def test_serial_sweep_is_exact_ilu0(golden, case, usescale):
+    m = _cases(golden)[case]()
+    if usescale and case.startswith("2dcyl1_bsr4_row"):
+        pytest.skip("getScalingVector reads (j*bs+j): layout independent, covered by col")
+    pl = O.ilu_positions(m)
+    f = O.ilu0_factorize(m, pl, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL, usescale=usescale,
+                         compute_info=True)
+    info = f["precinfo"]
+    # tests/solverops/async_ilu_convergence.cpp:574-575 asserts 5e-16 on its own cases (2dcyl1 CSR/BSR4,
+    # scaled and not); the synthetic block cases are ours and get rounding headroom
+    bound = 5e-16 if case.startswith("2dcyl1") or case == "poisson16_csr" else 2e-15
+    assert info[0] / info[1] < bound
+    # fixed point: a second sweep changes nothing beyond rounding (ibid. :357-375, fixed-point tests)
+    f2 = O.ilu0_factorize(m, pl, 2, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL, usescale=usescale)
+    den = np.abs(f["iluvals"]).max()
+    assert np.abs(f2["iluvals"] - f["iluvals"]).max() / den < 1e-13
+
+
+@pytest.mark.parametrize("case", ["2dcyl1_bsr4_col", "2dcyl1_bsr4_row", "msc_csr", "poisson8_bs8",
+                                  "poisson12_bs5"])
+def test_serial_sweep_equals_textbook_ilu0(golden, case):
+    m = _cases(golden)[case]()
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ZERO)
+    got = factor_blocks(m, f["iluvals"]).copy()
+    want = textbook_block_ilu0(m)
+    if m["bs"] > 1:  # block version leaves inverted diagonal blocks (async_blockilu_factor.cpp:143-146)
+        want[m["diagind"]] = np.linalg.inv(want[m["diagind"]])
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-10
+
+
+def test_scalar_zero_init_falls_through_to_original(golden):
+    """async_ilu_factor.cpp:48-54: missing break, so with 0 sweeps zero-init == original-init."""
+    m = _cases(golden)["msc_csr"]()
+    pl = O.ilu_positions(m)
+    f = O.ilu0_factorize(m, pl, 0, init=O.INIT_F_ZERO)
+    assert np.array_equal(f["iluvals"], m["vals"])
+    mb = _cases(golden)["2dcyl1_bsr4_col"]()
+    fb = O.ilu0_factorize(mb, None, 0, init=O.INIT_F_ZERO)
+    # block version: zeros, then the final diagonal inversion of a zero block -> non-finite
+    off = np.ones(mb["nnzb"], bool)
+    off[mb["diagind"]] = False
+    assert np.all(fb["iluvals"].reshape(-1, 16)[off] == 0)
+
+
+@pytest.mark.parametrize("case", ["2dcyl1_bsr4_col", "2dcyl1_csr", "poisson16_bs4"])
+@pytest.mark.parametrize("init", [O.INIT_F_ORIGINAL, O.INIT_F_SGS])
+def test_async_ilu_sweeps_converge_to_exact(golden, case, init):
+    """`ailu` tests, tests/solverops/CMakeLists.txt:6-60: async sweeps reach the serial factor."""
+    m = _cases(golden)[case]()
+    pl = O.ilu_positions(m)
+    exact = O.ilu0_factorize(m, pl, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL)["iluvals"]
+    den = np.abs(exact).max()
+    prev = np.inf
+    for mode, sweeps in ((O.JACOBI_SYNC, 60), (O.ASYNC_OMP, 60)):
+        got = O.ilu0_factorize(m, pl, sweeps, mode=mode, init=init, chunk=32)["iluvals"]
+        assert np.abs(got - exact).max() / den < 1e-12
+    # partial convergence after a few sweeps stays finite (the iteration is nonlinear: no monotonicity)
+    got = O.ilu0_factorize(m, pl, 3, mode=O.JACOBI_SYNC, init=init)["iluvals"]
+    assert np.all(np.isfinite(got))
+
+
+@pytest.mark.parametrize("case", ["2dcyl1_bsr4_col", "2dcyl1_bsr4_row", "2dcyl1_csr", "poisson16_bs4"])
+@pytest.mark.parametrize("init", [O.INIT_A_ZERO, O.INIT_A_JACOBI])
+def test_async_triangular_sweeps_converge_to_exact(golden, case, init):
+    """`triangular` tests, tests/solverops/async_triangular_factors_convergence.cpp:288-367; r = 1.1
+    as at :62."""
+    m = _cases(golden)[case]()
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL)["iluvals"]
+    r = np.full(m["nbrows"] * m["bs"], 1.1)
+    exact = O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL, init=init)
+    # exactness of the serial solve: (LU) z = r on the factor itself
+    fb = factor_blocks(m, f)
+    z = exact.reshape(-1, m["bs"])
+    bp, bc, dg = m["browptr"], m["bcolind"], m["diagind"]
+    # U z
+    uz = np.zeros_like(z)
+    for i in range(m["nbrows"]):
+        if m["bs"] > 1:
+            acc = np.linalg.solve(fb[dg[i]], z[i])
+        else:
+            acc = fb[dg[i]] @ z[i]
+        for p in range(dg[i] + 1, bp[i + 1]):
+            acc = acc + fb[p] @ z[bc[p]]
+        uz[i] = acc
+    luz = np.zeros_like(z)
+    for i in range(m["nbrows"]):
+        acc = uz[i].copy()
+        for p in range(bp[i], dg[i]):
+            acc = acc + fb[p] @ uz[bc[p]]
+        luz[i] = acc
+    assert np.abs(luz.reshape(-1) - r).max() < 1e-9 * max(1.0, np.abs(z).max())
+    nlev = 60 if case.startswith("poisson") else 30
+    for mode in (O.JACOBI_SYNC, O.ASYNC_OMP):
+        got = O.ilu0_apply(m, f, r, nlev, mode=mode, init=init, chunk=16)
+        assert np.abs(got - exact).max() / np.abs(exact).max() < 1e-15 * 10
+
+
+def test_ilu_apply_invalid_init_throws(golden):
+    m = W.poisson3d(6, 4)
+    f = O.ilu0_factorize(m, None, 1)["iluvals"]
+    with pytest.raises(RuntimeError):  # src/solverops_ilu0.cpp:125-126
+        O.ilu0_apply(m, f, np.ones(m["nbrows"] * 4), 1, init=O.INIT_A_NONE)
+
+
+# ------------------------------------------------------------------ G5: Jacobi / SGS
+
+@pytest.mark.parametrize("bs,rowmajor", [(1, False), (4, False), (4, True)])
+def test_sgs_serial_is_exact_sgs(golden, bs, rowmajor):
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), bs, rowmajor)
+    A = mtxio.bsr_to_scipy(m).toarray()
+    n = A.shape[0]
+    blk = np.kron(np.eye(m["nbrows"]), np.ones((bs, bs))) > 0
+    D = np.where(blk, A, 0.0)
+    rowb = np.arange(n)[:, None] // bs
+    colb = np.arange(n)[None, :] // bs
+    L = np.where(colb < rowb, A, 0.0)
+    U = np.where(colb > rowb, A, 0.0)
+    r = W.rhs_vector(n)
+    d = O.jacobi_compute(m)
+    assert np.abs(O.jacobi_apply(m, d, r) - np.linalg.solve(D, r)).max() < 1e-9
+    z = O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
+    want = np.linalg.solve(D + U, D @ np.linalg.solve(D + L, r))
+    assert np.abs(z - want).max() / np.abs(want).max() < 1e-10
+    # relaxation: one step = forward GS pass then backward GS pass from x0 = 0
+    x = O.sgs_relax(m, d, r, maxits=1, mode=O.GS_SERIAL)
+    x1 = np.linalg.solve(D + L, r)
+    x2 = np.linalg.solve(D + U, r - L @ x1)
+    assert np.abs(x - x2).max() / np.abs(x2).max() < 1e-10
+    # async backward sweeps converge to the serial result
+    for mode in (O.JACOBI_SYNC, O.ASYNC_OMP):
+        za = O.sgs_apply(m, d, r, 40, mode=mode, init=O.INIT_A_ZERO, chunk=16)
+        assert np.abs(za - z).max() / np.abs(z).max() < 1e-13
+
+
+# ------------------------------------------------------------------ G7: solve-level known answers
+
+SOLVE_CASES = [
+    # (name, matrix, bs, rowmajor, prec, solver_tol, test_tol, maxiter)  tests/CMakeLists.txt:34-173
+    ("SPDCSRJacobi", "msc00726", 1, False, "jacobi", 1e-10, 1e-9, 200),
+    ("SPDCSRSGS", "msc00726", 1, False, "sgs", 1e-10, 1e-10, 200),
+    ("SPDCSRILU0", "msc00726", 1, False, "ilu0", 1e-10, 1e-10, 200),
+    ("CSRJacobi", "2dcyl1", 1, False, "jacobi", 1e-10, 1e-8, 200),
+    ("CSRSGS", "2dcyl1", 1, False, "sgs", 1e-10, 1e-8, 200),
+    ("CSRILU0", "2dcyl1", 1, False, "ilu0", 1e-10, 1e-8, 200),
+    ("BSR4JacobiRowmajor", "2dcyl1", 4, True, "jacobi", 1e-10, 1e-8, 200),
+    ("BSR4SGSRowmajor", "2dcyl1", 4, True, "sgs", 1e-10, 1e-8, 200),
+    ("BSR4ILU0Rowmajor", "2dcyl1", 4, True, "ilu0", 1e-10, 1e-8, 200),
+    ("BSR4BiCGStabNoneColmajor", "2dcyl1", 4, False, "none", 1e-12, 1e-8, 1000),
+    ("BSR4JacobiColmajor", "2dcyl1", 4, False, "jacobi", 1e-10, 1e-8, 200),
+    ("BSR4SGSColmajor", "2dcyl1", 4, False, "sgs", 1e-10, 1e-8, 200),
+    ("BSR4ILU0Colmajor", "2dcyl1", 4, False, "ilu0", 1e-10, 1e-8, 200),
+]
+
+
+@pytest.mark.parametrize("name,mat,bs,rowmajor,prec,tol,testtol,maxiter", SOLVE_CASES,
+                         ids=[c[0] for c in SOLVE_CASES])
+def test_solve_known_answer(golden, name, mat, bs, rowmajor, prec, tol, testtol, maxiter):
+    m = mtxio.read_mtx_bsr(G(golden, mat + ".mtx"), bs, rowmajor)
+    b = mtxio.read_mtx_dense(G(golden, mat + "_b.mtx"))
+    xk = mtxio.read_mtx_dense(G(golden, mat + "_x.mtx"))
+    if prec == "none":
+        P = lambda v: v.copy()
+    elif prec == "jacobi":
+        d = O.jacobi_compute(m)
+        P = lambda v: O.jacobi_apply(m, d, v)
+    elif prec == "sgs":
+        d = O.jacobi_compute(m)
+        P = lambda v: O.sgs_apply(m, d, v, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
+    else:
+        # fact_init_type init_zero, 1 build sweep, 1 apply sweep at OMP_NUM_THREADS=1
+        init = O.INIT_F_ZERO if bs == 1 else O.INIT_F_ORIGINAL
+        f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=init)["iluvals"]
+        P = lambda v: O.ilu0_apply(m, f, v, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
+    # the reference's own parameters must converge within its max_iter ...
+    x, its, rel = bicgstab(lambda v: O.spmv(m, v), P, b, tol, maxiter)
+    assert rel < tol and its <= maxiter
+    # ... and the known-answer comparison of tests/testsolve.cpp:107-116.  With the reference's
+    # solver_tol the error sits within a factor 1-3 of test_tol and passes or fails on the last BiCGSTAB
+    # residual drop (cond(2dcyl1)=8e3, cond(msc00726)=4e5), so the comparison is made two digits
+    # tighter; msc00726's shipped x only satisfies ||A x - b|| = 1.5e-6, which floors its error at ~2e-9.
+    x, its, rel = bicgstab(lambda v: O.spmv(m, v), P, b, tol * 1e-4, 2 * maxiter)
+    floor = 2e-9 if mat == "msc00726" else 0.0
+    assert np.linalg.norm(x - xk) < max(testtol, floor)
+
+
+def test_threaded_bsr4_ilu0_colmajor(golden):
+    """ThreadedBSR4ILU0Colmajor, tests/CMakeLists.txt:165-173: init_zero, 10 build / 15 apply sweeps."""
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False)
+    b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
+    xk = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
+    # zero init for the block factorisation gives singular U_jj on the first sweep in a synchronous
+    # model; the reference test runs it threaded where it behaves as Gauss-Seidel.  Use the threaded mode.
+    f = O.ilu0_factorize(m, None, 10, mode=O.ASYNC_OMP, init=O.INIT_F_ORIGINAL, chunk=256)["iluvals"]
+    P = lambda v: O.ilu0_apply(m, f, v, 15, mode=O.ASYNC_OMP, init=O.INIT_A_ZERO, chunk=256)
+    x, its, rel = bicgstab(lambda v: O.spmv(m, v), P, b, 1e-10, 200)
+    assert rel < 1e-10 and its <= 200
+    x, its, rel = bicgstab(lambda v: O.spmv(m, v), P, b, 1e-13, 400)  # see test_solve_known_answer
+    assert np.linalg.norm(x - xk) < 1e-8
+
+
+def test_block_inflation_recipe_is_factorizable():
+    """before freezing the inflation constants confirm serial block-ILU(0) exists with
+    remainder/initial < 1e-15 at 16^3 and that the async iteration converges."""
+    m = W.poisson3d(16, 4, grid="uniform")
+    pl = O.ilu_positions(m)
+    f = O.ilu0_factorize(m, pl, 1, compute_info=True)
+    assert f["precinfo"][0] / f["precinfo"][1] < 1e-15
+    fa = O.ilu0_factorize(m, pl, 3, mode=O.ASYNC_OMP)
+    assert np.all(np.isfinite(fa["iluvals"]))
+
+
+def test_diag_dominance_and_precinfo(golden):
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False)
+    pl = O.ilu_positions(m)
+    f = O.ilu0_factorize(m, pl, 1, compute_info=True)
+    info = f["precinfo"]
+    # tests/testutils.cpp:297-308: remainder < initial, < 1e-11 at one thread, diag dominance <= 1
+    assert info[0] < info[1] and info[0] < 1e-11
+    assert info[2] <= 1 and info[3] <= 1 and info[4] <= 1 and info[5] <= 1
