@@ -1,0 +1,254 @@
+"""ctypes binding of include/blasted_hip.h (plumbing for tests and bench.py; the product boundary is
+the C ABI itself).  There is no fallback: if the shared library or a GPU is missing, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "lib", "libblasted_hip.so")
+
+OK, EINVAL, ENODEV, ERUNTIME, ESTATE, ENOTIMPL = 0, 1, 2, 3, 4, 5
+COLMAJOR, ROWMAJOR = 0, 1
+HOST, DEVICE = 0, 1
+ASYNC, JACOBI_SYNC = 0, 1
+INIT_F_ZERO, INIT_F_ORIGINAL, INIT_F_SGS, INIT_F_NONE = 0, 1, 2, 3
+INIT_A_ZERO, INIT_A_JACOBI, INIT_A_NONE = 0, 1, 2
+
+# every symbol include/blasted_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "blasted_hip_last_error", "blasted_hip_device_count", "blasted_hip_create", "blasted_hip_destroy",
+    "blasted_hip_synchronize", "blasted_hip_set_pattern", "blasted_hip_set_values",
+    "blasted_hip_ilu0_positions", "blasted_hip_ilu0_positions_size", "blasted_hip_ilu0_get_positions",
+    "blasted_hip_ilu0_factorize", "blasted_hip_ilu0_apply", "blasted_hip_jacobi_compute",
+    "blasted_hip_jacobi_apply", "blasted_hip_sgs_apply", "blasted_hip_sgs_relax", "blasted_hip_spmv",
+    "blasted_hip_gemv3", "blasted_hip_get_iluvals", "blasted_hip_get_dblocks", "blasted_hip_get_scale",
+    "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
+    "blasted_hip_get_timing",
+]
+
+_lib = None
+
+
+class BlastedHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("blasted_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise ImportError("libblasted_hip.so is not built (run __graft_entry__.build()): " + LIBPATH)
+        _lib = C.CDLL(LIBPATH)
+        _lib.blasted_hip_last_error.restype = C.c_char_p
+        vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+        _lib.blasted_hip_create.argtypes = [C.POINTER(vp), ci, vp]
+        _lib.blasted_hip_destroy.argtypes = [vp]
+        _lib.blasted_hip_synchronize.argtypes = [vp]
+        _lib.blasted_hip_set_pattern.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci]
+        _lib.blasted_hip_set_values.argtypes = [vp, vp, ci]
+        _lib.blasted_hip_ilu0_positions.argtypes = [vp]
+        _lib.blasted_hip_ilu0_positions_size.argtypes = [vp, C.POINTER(C.c_long)]
+        _lib.blasted_hip_ilu0_get_positions.argtypes = [vp, vp, vp, vp]
+        _lib.blasted_hip_ilu0_factorize.argtypes = [vp, ci, ci, ci, ci, vp]
+        _lib.blasted_hip_ilu0_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
+        _lib.blasted_hip_jacobi_compute.argtypes = [vp]
+        _lib.blasted_hip_jacobi_apply.argtypes = [vp, vp, vp, ci]
+        _lib.blasted_hip_sgs_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
+        _lib.blasted_hip_sgs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
+        _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
+        _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
+        for nm in ("iluvals", "dblocks", "scale", "ytemp"):
+            getattr(_lib, "blasted_hip_get_" + nm).argtypes = [vp, vp]
+        _lib.blasted_hip_iluvals_device.argtypes = [vp, C.POINTER(vp)]
+        _lib.blasted_hip_set_timing.argtypes = [vp, ci]
+        _lib.blasted_hip_get_timing.argtypes = [vp, vp, ci]
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise BlastedHipError(rc, lib().blasted_hip_last_error().decode())
+
+
+def _ptr(a):
+    """numpy array -> host pointer; torch tensor -> its data pointer; int -> as is; None -> NULL."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())
+
+
+def _loc(a):
+    if isinstance(a, np.ndarray):
+        return HOST
+    if hasattr(a, "is_cuda"):
+        return DEVICE if a.is_cuda else HOST
+    raise TypeError("expected a numpy array or a torch tensor")
+
+
+def device_count():
+    return int(lib().blasted_hip_device_count())
+
+
+class Prec:
+    """One blasted_hip_prec object.  Vectors may be float64 numpy arrays (host path) or float64 CUDA
+    torch tensors (device path, stream-ordered)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p(0)
+        _check(lib().blasted_hip_create(C.byref(self._h), int(device), C.c_void_p(stream or 0)))
+        self._keep = []
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().blasted_hip_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- matrix
+    def set_matrix(self, m):
+        """m: dict with nbrows, nnzb, bs, rowmajor, browptr, bcolind, diagind, vals (all numpy or all
+        CUDA torch tensors)."""
+        bp, bc, dg = m["browptr"], m["bcolind"], m["diagind"]
+        if isinstance(bp, np.ndarray):
+            bp, bc, dg = (np.ascontiguousarray(v, dtype=np.int32) for v in (bp, bc, dg))
+        self._keep = [bp, bc, dg]
+        _check(lib().blasted_hip_set_pattern(self._h, int(m["nbrows"]), int(m["nnzb"]), int(m["bs"]),
+                                             ROWMAJOR if m.get("rowmajor") else COLMAJOR,
+                                             _ptr(bp), _ptr(bc), _ptr(dg), _loc(bp)))
+        self.n = int(m["nbrows"]) * int(m["bs"])
+        self.nvals = int(m["nnzb"]) * int(m["bs"]) ** 2
+        self.nnzb = int(m["nnzb"])
+        self.bs = int(m["bs"])
+        self.nbrows = int(m["nbrows"])
+        self.set_values(m["vals"])
+
+    def set_values(self, vals):
+        if isinstance(vals, np.ndarray):
+            vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self._vals = vals
+        _check(lib().blasted_hip_set_values(self._h, _ptr(vals), _loc(vals)))
+
+    def synchronize(self):
+        _check(lib().blasted_hip_synchronize(self._h))
+
+    # -- ILU(0)
+    def ilu0_positions(self):
+        _check(lib().blasted_hip_ilu0_positions(self._h))
+        n = C.c_long(0)
+        _check(lib().blasted_hip_ilu0_positions_size(self._h, C.byref(n)))
+        posptr = np.zeros(self.nnzb + 1, np.int32)
+        lowerp = np.zeros(n.value, np.int32)
+        upperp = np.zeros(n.value, np.int32)
+        _check(lib().blasted_hip_ilu0_get_positions(self._h, _ptr(posptr), _ptr(lowerp), _ptr(upperp)))
+        return posptr, lowerp, upperp
+
+    def ilu0_factorize(self, nbuildsweeps, init=INIT_F_ORIGINAL, usescale=False, mode=ASYNC,
+                       compute_info=False):
+        info = np.zeros(6) if compute_info else None
+        _check(lib().blasted_hip_ilu0_factorize(self._h, int(nbuildsweeps), int(init), int(bool(usescale)),
+                                                int(mode), _ptr(info)))
+        return info
+
+    def _vec_out(self, like):
+        if isinstance(like, np.ndarray):
+            return np.zeros(self.n)
+        import torch
+        return torch.zeros(self.n, dtype=torch.float64, device=like.device)
+
+    @staticmethod
+    def _prep(v):
+        if isinstance(v, np.ndarray):
+            return np.ascontiguousarray(v, dtype=np.float64)
+        return v
+
+    def ilu0_apply(self, r, napplysweeps, init=INIT_A_ZERO, mode=ASYNC, out=None):
+        r = self._prep(r)
+        z = self._vec_out(r) if out is None else out
+        _check(lib().blasted_hip_ilu0_apply(self._h, _ptr(r), _ptr(z), int(napplysweeps), int(init),
+                                            int(mode), _loc(r)))
+        return z
+
+    # -- Jacobi / SGS
+    def jacobi_compute(self):
+        _check(lib().blasted_hip_jacobi_compute(self._h))
+
+    def jacobi_apply(self, r, out=None):
+        r = self._prep(r)
+        z = self._vec_out(r) if out is None else out
+        _check(lib().blasted_hip_jacobi_apply(self._h, _ptr(r), _ptr(z), _loc(r)))
+        return z
+
+    def sgs_apply(self, r, napplysweeps, init=INIT_A_ZERO, mode=ASYNC, out=None):
+        r = self._prep(r)
+        z = self._vec_out(r) if out is None else out
+        _check(lib().blasted_hip_sgs_apply(self._h, _ptr(r), _ptr(z), int(napplysweeps), int(init),
+                                           int(mode), _loc(r)))
+        return z
+
+    def sgs_relax(self, b, x, maxits, mode=ASYNC):
+        """x is updated in place and returned."""
+        b = self._prep(b)
+        _check(lib().blasted_hip_sgs_relax(self._h, _ptr(b), _ptr(x), int(maxits), int(mode), _loc(b)))
+        return x
+
+    # -- SpMV
+    def spmv(self, x, out=None):
+        x = self._prep(x)
+        y = self._vec_out(x) if out is None else out
+        _check(lib().blasted_hip_spmv(self._h, _ptr(x), _ptr(y), _loc(x)))
+        return y
+
+    def gemv3(self, a, x, b, y, out=None):
+        x, y = self._prep(x), self._prep(y)
+        z = self._vec_out(x) if out is None else out
+        _check(lib().blasted_hip_gemv3(self._h, float(a), _ptr(x), float(b), _ptr(y), _ptr(z), _loc(x)))
+        return z
+
+    # -- state read-back
+    def get_iluvals(self):
+        out = np.zeros(self.nvals)
+        _check(lib().blasted_hip_get_iluvals(self._h, _ptr(out)))
+        return out
+
+    def get_dblocks(self):
+        out = np.zeros(self.nbrows * self.bs * self.bs)
+        _check(lib().blasted_hip_get_dblocks(self._h, _ptr(out)))
+        return out
+
+    def get_scale(self):
+        out = np.zeros(self.n)
+        _check(lib().blasted_hip_get_scale(self._h, _ptr(out)))
+        return out
+
+    def get_ytemp(self):
+        out = np.zeros(self.n)
+        _check(lib().blasted_hip_get_ytemp(self._h, _ptr(out)))
+        return out
+
+    def iluvals_device_ptr(self):
+        p = C.c_void_p(0)
+        _check(lib().blasted_hip_iluvals_device(self._h, C.byref(p)))
+        return p.value
+
+    # -- timing
+    def set_timing(self, enable):
+        _check(lib().blasted_hip_set_timing(self._h, int(bool(enable))))
+
+    def get_timing(self, reset=True):
+        out = np.zeros(6)
+        _check(lib().blasted_hip_get_timing(self._h, _ptr(out), int(bool(reset))))
+        return {"lower_ms": out[0], "lower_launches": out[1], "upper_ms": out[2],
+                "upper_launches": out[3], "other_ms": out[4], "other_launches": out[5]}

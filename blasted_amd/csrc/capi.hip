@@ -1,0 +1,881 @@
+// capi.hip -- implementation of the C ABI declared in include/blasted_hip.h.
+// Host-side orchestration only: buffer ownership, sweep sequencing, init/prologue handling exactly
+// as the reference's operator methods do it (citations at each entry point).  All arithmetic is in
+// the kernel translation units; there is no CPU compute path in this library.
+#include "ctx.hpp"
+
+#include <cstring>
+#include <mutex>
+
+namespace bhip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg)
+{
+	g_last_error = msg;
+}
+
+template <typename T>
+static T *dev_alloc(size_t count)
+{
+	T *p = nullptr;
+	BHIP_CHECK(hipMalloc(&p, sizeof(T) * (count ? count : 1)));
+	return p;
+}
+
+static void dev_free(void *p)
+{
+	if (p)
+		(void)hipFree(p);
+}
+
+template <typename F>
+static int guarded(F &&f)
+{
+	try {
+		f();
+		return BLASTED_HIP_OK;
+	} catch (const HipFailure &e) {
+		return e.code;
+	} catch (const std::exception &e) {
+		set_error(std::string("unexpected exception: ") + e.what());
+		return BLASTED_HIP_ERUNTIME;
+	}
+}
+
+static void use_device(blasted_hip_prec p)
+{
+	if (!p)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "null blasted_hip_prec");
+	BHIP_CHECK(hipSetDevice(p->device));
+}
+
+static void need_pattern(blasted_hip_prec p)
+{
+	if (!p->have_pattern)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "set_pattern has not been called");
+}
+
+static void need_values(blasted_hip_prec p)
+{
+	need_pattern(p);
+	if (!p->vals)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "set_values has not been called");
+}
+
+static double *ensure(double *&buf, long count)
+{
+	if (!buf)
+		buf = dev_alloc<double>((size_t)count);
+	return buf;
+}
+
+// ---- timing ------------------------------------------------------------------------------
+
+static hipEvent_t take_event(Timing &t)
+{
+	if (!t.pool.empty()) {
+		hipEvent_t e = t.pool.back();
+		t.pool.pop_back();
+		return e;
+	}
+	hipEvent_t e;
+	BHIP_CHECK(hipEventCreate(&e));
+	return e;
+}
+
+static void fold_timing(blasted_hip_prec p)
+{
+	Timing &t = p->timing;
+	if (t.recs.empty())
+		return;
+	BHIP_CHECK(hipStreamSynchronize(p->stream));
+	for (auto &r : t.recs) {
+		float ms = 0;
+		BHIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+		t.ms[r.kind] += ms;
+		t.launches[r.kind] += r.launches;
+		t.pool.push_back(r.e0);
+		t.pool.push_back(r.e1);
+	}
+	t.recs.clear();
+}
+
+struct Phase {
+	blasted_hip_prec p;
+	int kind, launches = 0;
+	hipEvent_t e0 = nullptr;
+	Phase(blasted_hip_prec p_, int kind_) : p(p_), kind(kind_)
+	{
+		if (p->timing.enabled) {
+			if (p->timing.recs.size() >= 2048)
+				fold_timing(p);
+			e0 = take_event(p->timing);
+			BHIP_CHECK(hipEventRecord(e0, p->stream));
+		}
+	}
+	void done()
+	{
+		if (e0) {
+			hipEvent_t e1 = take_event(p->timing);
+			BHIP_CHECK(hipEventRecord(e1, p->stream));
+			p->timing.recs.push_back({e0, e1, kind, launches});
+			e0 = nullptr;
+		}
+	}
+};
+
+// ---- host <-> device vector staging --------------------------------------------------------
+
+// Returns a device pointer holding the caller's input vector.
+static const double *in_vec(blasted_hip_prec p, const double *v, int loc, int slot)
+{
+	if (loc == BLASTED_HIP_DEVICE)
+		return v;
+	double *d = ensure(p->stage[slot], p->n());
+	BHIP_CHECK(hipMemcpyAsync(d, v, sizeof(double) * p->n(), hipMemcpyHostToDevice, p->stream));
+	return d;
+}
+
+static double *out_vec(blasted_hip_prec p, double *v, int loc, int slot)
+{
+	if (loc == BLASTED_HIP_DEVICE)
+		return v;
+	return ensure(p->stage[slot], p->n());
+}
+
+static void finish_out(blasted_hip_prec p, double *host, const double *dev, int loc)
+{
+	if (loc == BLASTED_HIP_DEVICE)
+		return;
+	BHIP_CHECK(hipMemcpyAsync(host, dev, sizeof(double) * p->n(), hipMemcpyDeviceToHost, p->stream));
+	BHIP_CHECK(hipStreamSynchronize(p->stream));
+}
+
+static void check_loc(int loc)
+{
+	if (loc != BLASTED_HIP_HOST && loc != BLASTED_HIP_DEVICE)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "loc must be BLASTED_HIP_HOST or BLASTED_HIP_DEVICE");
+}
+
+static void check_mode(int mode)
+{
+	if (mode != BLASTED_HIP_ASYNC && mode != BLASTED_HIP_JACOBI_SYNC)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC or BLASTED_HIP_JACOBI_SYNC");
+}
+
+static SweepArgs base_args(blasted_hip_prec p)
+{
+	SweepArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.pat = p->pat;
+	a.a = 1.0;
+	a.b = 0.0;
+	return a;
+}
+
+// `nsweeps` sweeps of one operator on iterate `x`.
+// ASYNC: in place.  JACOBI_SYNC: ping-pong between x and `other`; first_in (optional) is read by the
+// first sweep instead of x.  Returns the buffer holding the final iterate (x or other).
+static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSrc dsrc, double *x,
+                          double *other, const double *first_in, int nsweeps, int mode, int kind)
+{
+	Phase ph(p, kind);
+	double *cur = x;
+	for (int s = 0; s < nsweeps; s++) {
+		const double *in = (s == 0 && first_in) ? first_in : cur;
+		double *out;
+		if (mode == BLASTED_HIP_ASYNC)
+			out = x;
+		else
+			out = (s == 0 && first_in) ? x : (cur == x ? other : x);
+		a.xin = in;
+		a.xout = out;
+		launch_sweep(a, part, post, dsrc, p->stream);
+		ph.launches++;
+		cur = out;
+	}
+	ph.done();
+	return cur;
+}
+
+}  // namespace bhip
+
+using namespace bhip;
+
+extern "C" {
+
+const char *blasted_hip_last_error(void)
+{
+	return g_last_error.c_str();
+}
+
+int blasted_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int blasted_hip_create(blasted_hip_prec *out, int device, void *stream)
+{
+	return guarded([&] {
+		if (!out)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "null output handle");
+		*out = nullptr;
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+			BHIP_FAIL(BLASTED_HIP_ENODEV, "no HIP device available: the MI355X backend has no CPU fallback");
+		if (device < 0 || device >= n)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "device index out of range");
+		BHIP_CHECK(hipSetDevice(device));
+		auto *p = new blasted_hip_prec_s();
+		p->device = device;
+		if (stream) {
+			p->stream = (hipStream_t)stream;
+			p->own_stream = false;
+		} else {
+			BHIP_CHECK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+			p->own_stream = true;
+		}
+		*out = p;
+	});
+}
+
+int blasted_hip_destroy(blasted_hip_prec p)
+{
+	return guarded([&] {
+		if (!p)
+			return;
+		(void)hipSetDevice(p->device);
+		(void)hipStreamSynchronize(p->stream);
+		for (auto &r : p->timing.recs) {
+			(void)hipEventDestroy(r.e0);
+			(void)hipEventDestroy(r.e1);
+		}
+		for (auto e : p->timing.pool)
+			(void)hipEventDestroy(e);
+		dev_free(p->browptr_own);
+		dev_free(p->bcolind_own);
+		dev_free(p->diagind_own);
+		dev_free(p->vals_own);
+		dev_free(p->posptr);
+		dev_free(p->lowerp);
+		dev_free(p->upperp);
+		dev_free(p->iluvals);
+		dev_free(p->iluvals2);
+		dev_free(p->scale);
+		dev_free(p->ytemp);
+		dev_free(p->dblocks);
+		for (int i = 0; i < 3; i++) {
+			dev_free(p->tmp[i]);
+			dev_free(p->stage[i]);
+		}
+		dev_free(p->red);
+		if (p->own_stream)
+			(void)hipStreamDestroy(p->stream);
+		delete p;
+	});
+}
+
+int blasted_hip_synchronize(blasted_hip_prec p)
+{
+	return guarded([&] {
+		use_device(p);
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+	});
+}
+
+int blasted_hip_set_pattern(blasted_hip_prec p, int nbrows, int nnzb, int bs, int layout,
+                            const int *browptr, const int *bcolind, const int *diagind, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		if (p->have_pattern)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "the sparsity pattern of an operator is set once");
+		if (nbrows < 0 || nnzb < 0 || !browptr || !bcolind || !diagind)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "set_pattern: null array or negative size");
+		if (layout != BLASTED_HIP_COLMAJOR && layout != BLASTED_HIP_ROWMAJOR)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "Block ordering must be either rowmajor or colmajor!");
+		if (!sweep_supported(bs))
+			BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "Block size " + std::to_string(bs) + " not supported");
+		if ((double)nnzb * bs * bs >= 2147483647.0 * 16)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "matrix too large");
+		Pattern pat;
+		pat.nbrows = nbrows;
+		pat.nnzb = nnzb;
+		pat.bs = bs;
+		pat.rowmajor = (layout == BLASTED_HIP_ROWMAJOR) ? 1 : 0;
+		if (loc == BLASTED_HIP_DEVICE) {
+			pat.browptr = browptr;
+			pat.bcolind = bcolind;
+			pat.diagind = diagind;
+		} else {
+			p->browptr_own = dev_alloc<int>((size_t)nbrows + 1);
+			p->bcolind_own = dev_alloc<int>((size_t)nnzb);
+			p->diagind_own = dev_alloc<int>((size_t)nbrows);
+			BHIP_CHECK(hipMemcpyAsync(p->browptr_own, browptr, sizeof(int) * ((size_t)nbrows + 1),
+			                          hipMemcpyHostToDevice, p->stream));
+			BHIP_CHECK(hipMemcpyAsync(p->bcolind_own, bcolind, sizeof(int) * (size_t)nnzb,
+			                          hipMemcpyHostToDevice, p->stream));
+			BHIP_CHECK(hipMemcpyAsync(p->diagind_own, diagind, sizeof(int) * (size_t)nbrows,
+			                          hipMemcpyHostToDevice, p->stream));
+			pat.browptr = p->browptr_own;
+			pat.bcolind = p->bcolind_own;
+			pat.diagind = p->diagind_own;
+		}
+		const int flags = validate_pattern_device(pat, p->stream);
+		if (flags) {
+			std::string msg = "set_pattern: invalid sparse-row pattern:";
+			if (flags & 8) msg += " [browptr not monotone / wrong nnzb]";
+			if (flags & 4) msg += " [column index out of range]";
+			if (flags & 1) msg += " [block columns not strictly ascending inside a row]";
+			if (flags & 2) msg += " [diagind does not address the diagonal block of its row]";
+			dev_free(p->browptr_own);
+			dev_free(p->bcolind_own);
+			dev_free(p->diagind_own);
+			p->browptr_own = p->bcolind_own = p->diagind_own = nullptr;
+			BHIP_FAIL(BLASTED_HIP_EINVAL, msg);
+		}
+		p->pat = pat;
+		p->have_pattern = true;
+	});
+}
+
+int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		need_pattern(p);
+		if (!vals)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "set_values: null array");
+		if (loc == BLASTED_HIP_DEVICE) {
+			p->vals = vals;
+		} else {
+			if (!p->vals_own)
+				p->vals_own = dev_alloc<double>((size_t)p->nvals());
+			BHIP_CHECK(hipMemcpyAsync(p->vals_own, vals, sizeof(double) * (size_t)p->nvals(),
+			                          hipMemcpyHostToDevice, p->stream));
+			BHIP_CHECK(hipStreamSynchronize(p->stream));
+			p->vals = p->vals_own;
+		}
+	});
+}
+
+/* ---- ILU(0) ------------------------------------------------------------------------------ */
+
+int blasted_hip_ilu0_positions(blasted_hip_prec p)
+{
+	return guarded([&] {
+		use_device(p);
+		need_pattern(p);
+		if (p->npairs >= 0)
+			return;  // once per pattern, src/solverops_ilu0.cpp:193-196
+		Phase ph(p, 2);
+		p->npairs = run_ilu_positions(p->pat, &p->posptr, &p->lowerp, &p->upperp, p->stream);
+		ph.launches = 3;
+		ph.done();
+	});
+}
+
+int blasted_hip_ilu0_positions_size(blasted_hip_prec p, long *npairs)
+{
+	return guarded([&] {
+		use_device(p);
+		if (p->npairs < 0 || !npairs)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_positions has not been computed");
+		*npairs = p->npairs;
+	});
+}
+
+int blasted_hip_ilu0_get_positions(blasted_hip_prec p, int *posptr, int *lowerp, int *upperp)
+{
+	return guarded([&] {
+		use_device(p);
+		if (p->npairs < 0)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_positions has not been computed");
+		BHIP_CHECK(hipMemcpyAsync(posptr, p->posptr, sizeof(int) * ((size_t)p->pat.nnzb + 1),
+		                          hipMemcpyDeviceToHost, p->stream));
+		if (p->npairs > 0) {
+			BHIP_CHECK(hipMemcpyAsync(lowerp, p->lowerp, sizeof(int) * (size_t)p->npairs,
+			                          hipMemcpyDeviceToHost, p->stream));
+			BHIP_CHECK(hipMemcpyAsync(upperp, p->upperp, sizeof(int) * (size_t)p->npairs,
+			                          hipMemcpyDeviceToHost, p->stream));
+		}
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+	});
+}
+
+int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_init, int use_scaling,
+                               int mode, double *precinfo)
+{
+	return guarded([&] {
+		use_device(p);
+		need_values(p);
+		check_mode(mode);
+		if (nbuildsweeps < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "negative sweep count");
+		if (fact_init < BLASTED_HIP_INIT_F_ZERO || fact_init > BLASTED_HIP_INIT_F_NONE)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "Factor initialization not recongnized!");
+		const Pattern &pat = p->pat;
+		const long nv = p->nvals();
+
+		// first-time setup, src/solverops_ilu0.cpp:150-183,190-196
+		if (p->npairs < 0)
+			p->npairs = run_ilu_positions(pat, &p->posptr, &p->lowerp, &p->upperp, p->stream);
+		if (!p->iluvals) {
+			p->iluvals = dev_alloc<double>((size_t)nv);
+			BHIP_CHECK(hipMemcpyAsync(p->iluvals, p->vals, sizeof(double) * (size_t)nv,
+			                          hipMemcpyDeviceToDevice, p->stream));
+		}
+		if (!p->ytemp) {
+			p->ytemp = dev_alloc<double>((size_t)p->n());
+			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, sizeof(double) * (size_t)p->n(), p->stream));
+		}
+		if (use_scaling) {
+			ensure(p->scale, p->n());
+			launch_scaling_vector(pat, p->vals, p->scale, p->stream);
+		}
+		p->scaled = use_scaling != 0;
+		const double *scale = use_scaling ? p->scale : nullptr;
+
+		double *dscratch = nullptr;
+		if (fact_init == BLASTED_HIP_INIT_F_SGS)
+			dscratch = ensure(p->dblocks, (long)pat.nbrows * pat.bs * pat.bs);
+		launch_fact_init(pat, p->vals, scale, fact_init, p->iluvals, dscratch, p->stream);
+		if (fact_init == BLASTED_HIP_INIT_F_SGS)
+			p->jacobi_done = false;  // dblocks was used as scratch
+
+		FactorArgs fa;
+		fa.pat = pat;
+		fa.avals = p->vals;
+		fa.scale = scale;
+		fa.posptr = p->posptr;
+		fa.lowerp = p->lowerp;
+		fa.upperp = p->upperp;
+
+		const long ngroups = (long)pat.nbrows + 8;
+		if (precinfo) {
+			for (int i = 0; i < 6; i++)
+				precinfo[i] = 0;
+			ensure(p->red, ngroups * 4);
+			fa.in = p->iluvals;
+			fa.out = nullptr;
+			precinfo[1] = run_nonlinear_res(fa, p->red, p->stream);
+		}
+
+		// async_bilu0_sweeps, src/async_blockilu_factor.cpp:186-204
+		double *cur = p->iluvals;
+		{
+			Phase ph(p, 0);
+			for (int s = 0; s < nbuildsweeps; s++) {
+				double *out = cur;
+				if (mode == BLASTED_HIP_JACOBI_SYNC) {
+					if (!p->iluvals2)
+						p->iluvals2 = dev_alloc<double>((size_t)nv);
+					out = (cur == p->iluvals) ? p->iluvals2 : p->iluvals;
+				}
+				fa.in = cur;
+				fa.out = out;
+				launch_factor_sweep(fa, p->stream);
+				ph.launches++;
+				cur = out;
+			}
+			ph.done();
+		}
+		if (cur != p->iluvals)
+			BHIP_CHECK(hipMemcpyAsync(p->iluvals, cur, sizeof(double) * (size_t)nv,
+			                          hipMemcpyDeviceToDevice, p->stream));
+
+		if (precinfo) {
+			fa.in = p->iluvals;
+			fa.out = nullptr;
+			precinfo[0] = run_nonlinear_res(fa, p->red, p->stream);
+			double dd[4];
+			run_diag_dominance(pat, p->iluvals, p->red, dd, p->stream);
+			precinfo[5] = dd[0];
+			precinfo[4] = dd[1];
+			precinfo[3] = dd[2];
+			precinfo[2] = dd[3];
+		}
+
+		// block version only: invert diagonal blocks in place, src/async_blockilu_factor.cpp:143-146
+		if (pat.bs > 1) {
+			Phase ph(p, 2);
+			launch_invert_diag_blocks(pat, p->iluvals, 1, p->iluvals, 1, p->stream);
+			ph.launches = 1;
+			ph.done();
+		}
+		p->factored = true;
+	});
+}
+
+int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
+                           int apply_init, int mode, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		check_mode(mode);
+		need_pattern(p);
+		if (!p->factored)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_apply before ilu0_factorize");
+		if (apply_init != BLASTED_HIP_INIT_A_ZERO && apply_init != BLASTED_HIP_INIT_A_JACOBI)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, " scalar_ilu0_apply: Invalid init type!");
+		if (!r || !z || napplysweeps < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_apply: null vector or negative sweep count");
+		const long n = p->n();
+		const size_t nbytes = sizeof(double) * (size_t)n;
+		const double *dr = in_vec(p, r, loc, 0);
+		double *dz = out_vec(p, z, loc, 1);
+		const bool scalar = p->pat.bs == 1;
+		const bool jac = mode == BLASTED_HIP_JACOBI_SYNC;
+
+		// y := 0 (both init types), src/solverops_ilu0.cpp:83-94.  The prologue z := S r is fused: the
+		// lower sweeps read r (times scale) directly as their right-hand side.
+		{
+			Phase ph(p, 2);
+			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
+			ph.launches = 1;
+			ph.done();
+		}
+		SweepArgs a = base_args(p);
+		a.vals = p->iluvals;
+		a.rhs = dr;
+		a.rscale = p->scaled ? p->scale : nullptr;
+		a.descending = 0;
+		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
+		double *y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, nullptr,
+		                       napplysweeps, mode, 0);
+		double *yfree = (y == p->ytemp) ? yother : p->ytemp;  // Jacobi mode: the non-final y buffer
+
+		// z := y or z := 0, then upper sweeps, src/solverops_ilu0.cpp:110-141
+		a = base_args(p);
+		a.vals = p->iluvals;
+		a.dvals = p->iluvals;
+		a.rhs = y;
+		a.descending = 1;
+		const DSrc dsrc = scalar ? D_RECIP_DIAG : D_VALS_DIAG;
+		double *zfinal = dz;
+		if (napplysweeps == 0) {
+			Phase ph(p, 2);
+			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
+				BHIP_CHECK(hipMemcpyAsync(dz, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
+			else
+				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
+			ph.launches = 1;
+			ph.done();
+		} else if (!jac) {
+			const double *first_in = nullptr;
+			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
+				first_in = y;  // z0 = y: the first sweep gathers from y, no copy needed
+			else {
+				Phase ph(p, 2);
+				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
+				ph.launches = 1;
+				ph.done();
+			}
+			run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, nullptr, first_in, napplysweeps, mode, 1);
+		} else {
+			const double *first_in = y;
+			if (apply_init == BLASTED_HIP_INIT_A_ZERO) {
+				BHIP_CHECK(hipMemsetAsync(yfree, 0, nbytes, p->stream));
+				first_in = yfree;
+			}
+			// sweep 1: first_in -> dz ; sweep 2: dz -> zo ; ...  (zo must differ from y and first_in)
+			double *zo = ensure(p->tmp[1], n);
+			zfinal = run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, zo, first_in, napplysweeps, mode, 1);
+			if (zfinal != dz) {
+				BHIP_CHECK(hipMemcpyAsync(dz, zfinal, nbytes, hipMemcpyDeviceToDevice, p->stream));
+				zfinal = dz;
+			}
+		}
+		if (y != p->ytemp)  // keep the operator's ytemp = L^-1 r as the reference leaves it
+			BHIP_CHECK(hipMemcpyAsync(p->ytemp, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
+		if (p->scaled) {  // z := S z, src/solverops_ilu0.cpp:143-147
+			Phase ph(p, 2);
+			launch_scale_vec(dz, p->scale, n, p->stream);
+			ph.launches = 1;
+			ph.done();
+		}
+		finish_out(p, z, dz, loc);
+	});
+}
+
+/* ---- Jacobi / SGS ------------------------------------------------------------------------ */
+
+int blasted_hip_jacobi_compute(blasted_hip_prec p)
+{
+	return guarded([&] {
+		use_device(p);
+		need_values(p);
+		ensure(p->dblocks, (long)p->pat.nbrows * p->pat.bs * p->pat.bs);
+		Phase ph(p, 2);
+		launch_invert_diag_blocks(p->pat, p->vals, 1, p->dblocks, 0, p->stream);
+		ph.launches = 1;
+		ph.done();
+		p->jacobi_done = true;
+		if (!p->ytemp) {  // AsyncBlockSGS::compute, src/solverops_sgs.cpp:33-45
+			p->ytemp = dev_alloc<double>((size_t)p->n());
+			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, sizeof(double) * (size_t)p->n(), p->stream));
+		}
+	});
+}
+
+static void need_jacobi(blasted_hip_prec p)
+{
+	need_values(p);
+	if (!p->jacobi_done)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "jacobi_compute has not been called (or its dblocks were reused)");
+}
+
+int blasted_hip_jacobi_apply(blasted_hip_prec p, const double *r, double *z, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		need_jacobi(p);
+		if (!r || !z)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "null vector");
+		const double *dr = in_vec(p, r, loc, 0);
+		double *dz = out_vec(p, z, loc, 1);
+		SweepArgs a = base_args(p);
+		a.vals = p->vals;
+		a.dvals = p->dblocks;
+		a.rhs = dr;
+		run_sweeps(p, a, PART_NONE, POST_D_SUB, D_DBLOCKS, dz, nullptr, dr, 1, BLASTED_HIP_ASYNC, 0);
+		finish_out(p, z, dz, loc);
+	});
+}
+
+int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
+                          int apply_init, int mode, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		check_mode(mode);
+		need_jacobi(p);
+		if (!r || !z || napplysweeps < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_apply: null vector or negative sweep count");
+		if (apply_init < BLASTED_HIP_INIT_A_ZERO || apply_init > BLASTED_HIP_INIT_A_NONE)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "Apply initialization not recongnized!");
+		const long n = p->n();
+		const size_t nbytes = sizeof(double) * (size_t)n;
+		const bool jac = mode == BLASTED_HIP_JACOBI_SYNC;
+		const double *dr = in_vec(p, r, loc, 0);
+		double *dz;
+		if (loc == BLASTED_HIP_DEVICE)
+			dz = z;
+		else {
+			dz = ensure(p->stage[1], n);
+			if (apply_init == BLASTED_HIP_INIT_A_NONE)  // z is the initial guess of the backward sweeps
+				BHIP_CHECK(hipMemcpyAsync(dz, z, nbytes, hipMemcpyHostToDevice, p->stream));
+		}
+		const bool reinit = apply_init == BLASTED_HIP_INIT_A_JACOBI || apply_init == BLASTED_HIP_INIT_A_ZERO;
+		if (reinit) {  // src/solverops_sgs.cpp:57-60
+			Phase ph(p, 2);
+			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
+			ph.launches = 1;
+			ph.done();
+		}
+		// forward sweeps ytemp := D^-1 (r - L ytemp), src/solverops_sgs.cpp:62-66
+		SweepArgs a = base_args(p);
+		a.vals = p->vals;
+		a.dvals = p->dblocks;
+		a.rhs = dr;
+		a.descending = 0;
+		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
+		double *y = run_sweeps(p, a, PART_LOWER, POST_D_SUB, D_DBLOCKS, p->ytemp, yother, nullptr,
+		                       napplysweeps, mode, 0);
+		if (y != p->ytemp) {
+			BHIP_CHECK(hipMemcpyAsync(p->ytemp, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
+			y = p->ytemp;
+		}
+		// z init, src/solverops_sgs.cpp:68-75, then backward sweeps z := y - D^-1 U z, :77-82
+		a = base_args(p);
+		a.vals = p->vals;
+		a.dvals = p->dblocks;
+		a.rhs = y;
+		a.descending = 1;
+		const double *first_in = nullptr;
+		if (apply_init == BLASTED_HIP_INIT_A_JACOBI) {
+			if (napplysweeps == 0)
+				BHIP_CHECK(hipMemcpyAsync(dz, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
+			else
+				first_in = y;
+		} else if (apply_init == BLASTED_HIP_INIT_A_ZERO) {
+			Phase ph(p, 2);
+			BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
+			ph.launches = 1;
+			ph.done();
+		}
+		double *zo = jac ? ensure(p->tmp[1], n) : nullptr;
+		if (jac && !first_in && napplysweeps > 0) {
+			// synchronous sweeps need the initial z in a buffer that is not written by sweep 1
+			BHIP_CHECK(hipMemcpyAsync(p->tmp[0] ? p->tmp[0] : ensure(p->tmp[0], n), dz, nbytes,
+			                          hipMemcpyDeviceToDevice, p->stream));
+			first_in = p->tmp[0];
+		}
+		double *zfinal = run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, zo, first_in,
+		                            napplysweeps, mode, 1);
+		if (zfinal != dz)
+			BHIP_CHECK(hipMemcpyAsync(dz, zfinal, nbytes, hipMemcpyDeviceToDevice, p->stream));
+		finish_out(p, z, dz, loc);
+	});
+}
+
+int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int mode, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		check_mode(mode);
+		need_jacobi(p);
+		if (!b || !x || maxits < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_relax: null vector or negative iteration count");
+		const long n = p->n();
+		const size_t nbytes = sizeof(double) * (size_t)n;
+		const double *db = in_vec(p, b, loc, 0);
+		double *dx;
+		if (loc == BLASTED_HIP_DEVICE)
+			dx = x;
+		else {
+			dx = ensure(p->stage[1], n);
+			BHIP_CHECK(hipMemcpyAsync(dx, x, nbytes, hipMemcpyHostToDevice, p->stream));
+		}
+		SweepArgs a = base_args(p);
+		a.vals = p->vals;
+		a.dvals = p->dblocks;
+		a.rhs = db;
+		double *other = (mode == BLASTED_HIP_JACOBI_SYNC) ? ensure(p->tmp[0], n) : nullptr;
+		double *cur = dx;
+		// src/solverops_sgs.cpp:96-115: per step an ascending and a descending pass
+		for (int step = 0; step < maxits; step++) {
+			for (int dir = 0; dir < 2; dir++) {
+				a.descending = dir;
+				double *o = (mode == BLASTED_HIP_JACOBI_SYNC) ? (cur == dx ? other : dx) : dx;
+				Phase ph(p, dir);
+				a.xin = cur;
+				a.xout = o;
+				launch_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, p->stream);
+				ph.launches = 1;
+				ph.done();
+				cur = o;
+			}
+		}
+		if (cur != dx)
+			BHIP_CHECK(hipMemcpyAsync(dx, cur, nbytes, hipMemcpyDeviceToDevice, p->stream));
+		finish_out(p, x, dx, loc);
+	});
+}
+
+/* ---- SpMV --------------------------------------------------------------------------------- */
+
+int blasted_hip_gemv3(blasted_hip_prec p, double a_, const double *x, double b_, const double *y,
+                      double *z, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		need_values(p);
+		if (!x || !z || (b_ != 0.0 && !y))
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "gemv3: null vector");
+		if (x == z)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "gemv3: x must not alias z");
+		const double *dx = in_vec(p, x, loc, 0);
+		const double *dy = (b_ != 0.0) ? in_vec(p, y, loc, 2) : nullptr;
+		double *dz = out_vec(p, z, loc, 1);
+		SweepArgs a = base_args(p);
+		a.vals = p->vals;
+		a.rhs = dy;
+		a.a = a_;
+		a.b = b_;
+		run_sweeps(p, a, PART_ALL, POST_AXPBY, D_NONE, dz, nullptr, dx, 1, BLASTED_HIP_ASYNC, 0);
+		finish_out(p, z, dz, loc);
+	});
+}
+
+int blasted_hip_spmv(blasted_hip_prec p, const double *x, double *y, int loc)
+{
+	return blasted_hip_gemv3(p, 1.0, x, 0.0, nullptr, y, loc);
+}
+
+/* ---- read-back ---------------------------------------------------------------------------- */
+
+static int get_array(blasted_hip_prec p, const double *dev, long count, double *out, const char *what)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!dev || !out)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, std::string(what) + " is not available");
+		BHIP_CHECK(hipMemcpyAsync(out, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, p->stream));
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+	});
+}
+
+int blasted_hip_get_iluvals(blasted_hip_prec p, double *out)
+{
+	return get_array(p, p ? p->iluvals : nullptr, p ? p->nvals() : 0, out, "iluvals");
+}
+
+int blasted_hip_get_dblocks(blasted_hip_prec p, double *out)
+{
+	return get_array(p, p ? p->dblocks : nullptr, p ? (long)p->pat.nbrows * p->pat.bs * p->pat.bs : 0, out,
+	                 "dblocks");
+}
+
+int blasted_hip_get_scale(blasted_hip_prec p, double *out)
+{
+	return get_array(p, p ? p->scale : nullptr, p ? p->n() : 0, out, "scale");
+}
+
+int blasted_hip_get_ytemp(blasted_hip_prec p, double *out)
+{
+	return get_array(p, p ? p->ytemp : nullptr, p ? p->n() : 0, out, "ytemp");
+}
+
+int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!p->iluvals || !dev_ptr)
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "iluvals is not available");
+		*dev_ptr = p->iluvals;
+	});
+}
+
+/* ---- timing -------------------------------------------------------------------------------- */
+
+int blasted_hip_set_timing(blasted_hip_prec p, int enable)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!enable)
+			fold_timing(p);
+		p->timing.enabled = enable != 0;
+	});
+}
+
+int blasted_hip_get_timing(blasted_hip_prec p, double *out6, int reset)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!out6)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "null output");
+		fold_timing(p);
+		for (int k = 0; k < 3; k++) {
+			out6[2 * k] = p->timing.ms[k];
+			out6[2 * k + 1] = p->timing.launches[k];
+		}
+		if (reset)
+			for (int k = 0; k < 3; k++)
+				p->timing.ms[k] = p->timing.launches[k] = 0;
+	});
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// ctx.hpp -- internal state of one blasted_hip_prec object and the launch interface between the
+// C-ABI translation unit (capi.hip) and the kernel translation units.  Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/blasted_hip.h"
+
+namespace bhip {
+
+void set_error(const std::string &msg);
+
+struct HipFailure {
+	int code;
+};
+
+#define BHIP_CHECK(expr)                                                                        \
+	do {                                                                                        \
+		hipError_t e_ = (expr);                                                                 \
+		if (e_ != hipSuccess) {                                                                 \
+			::bhip::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
+			throw ::bhip::HipFailure{BLASTED_HIP_ERUNTIME};                                      \
+		}                                                                                       \
+	} while (0)
+
+#define BHIP_FAIL(code_, msg_)                  \
+	do {                                        \
+		::bhip::set_error(msg_);                \
+		throw ::bhip::HipFailure{code_};        \
+	} while (0)
+
+// Which stored blocks of a block-row a sweep visits
+enum Part { PART_LOWER = 0, PART_UPPER = 1, PART_OFFDIAG = 2, PART_ALL = 3, PART_NONE = 4 };
+// What is done with acc = sum_j A_ij x_j
+enum Post {
+	POST_SUB = 0,      // out = rhs - acc                         (unit lower solve)
+	POST_D_SUB = 1,    // out = D (rhs - acc)                     (upper solve, forward GS, relaxation)
+	POST_SUB_D = 2,    // out = rhs - D acc                       (backward GS)
+	POST_AXPBY = 3     // out = a acc + b y                       (SpMV, gemv3)
+};
+// Where D comes from
+enum DSrc {
+	D_NONE = 0,
+	D_VALS_DIAG = 1,   // the (already inverted) diagonal block of the factor, vals[diagind[i]]
+	D_DBLOCKS = 2,     // separate array of inverted diagonal blocks, dblocks[i]
+	D_RECIP_DIAG = 3   // scalar ILU: 1 / vals[diagind[i]]
+};
+
+struct Pattern {
+	int nbrows = 0, nnzb = 0, bs = 0, rowmajor = 0;
+	const int *browptr = nullptr, *bcolind = nullptr, *diagind = nullptr;
+};
+
+struct SweepArgs {
+	Pattern pat;
+	const double *vals;     // block values the sweep multiplies with
+	const double *dvals;    // D source array (vals or dblocks), may be null
+	const double *rhs;      // right-hand side (or y of gemv3), may be null for POST_AXPBY with b==0
+	const double *rscale;   // optional elementwise factor on rhs (z = S r fused into the sweep)
+	const double *xin;      // gathered iterate
+	double *xout;           // written iterate (== xin for in-place async sweeps)
+	double a, b;            // POST_AXPBY coefficients
+	int descending;         // row order of the sweep
+};
+
+struct FactorArgs {
+	Pattern pat;
+	const double *avals;    // original matrix values
+	const double *scale;    // symmetric scaling vector or null
+	const int *posptr, *lowerp, *upperp;
+	const double *in;       // factor values read
+	double *out;            // factor values written (== in for async)
+};
+
+// kernels_sweep.hip
+void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+bool sweep_supported(int bs);
+// kernels_factor.hip
+void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
+void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,
+                               double *dst, long dst_is_indexed_by_diag, hipStream_t s);
+void launch_fact_init(const Pattern &pat, const double *avals, const double *scale, int init_type,
+                      double *iluvals, double *dblk_scratch, hipStream_t s);
+void launch_scaling_vector(const Pattern &pat, const double *vals, double *scale, hipStream_t s);
+double run_nonlinear_res(const FactorArgs &a, double *dev_scratch, hipStream_t s);
+void run_diag_dominance(const Pattern &pat, const double *fvals, double *dev_scratch, double *out4,
+                        hipStream_t s);
+// kernels_aux.hip
+long run_ilu_positions(const Pattern &pat, int **posptr, int **lowerp, int **upperp, hipStream_t s);
+void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s);
+int validate_pattern_device(const Pattern &pat, hipStream_t s);
+
+struct Timing {
+	struct Rec {
+		hipEvent_t e0, e1;
+		int kind;
+		int launches;
+	};
+	bool enabled = false;
+	std::vector<Rec> recs;
+	std::vector<hipEvent_t> pool;
+	double ms[3] = {0, 0, 0};
+	double launches[3] = {0, 0, 0};
+};
+
+}  // namespace bhip
+
+struct blasted_hip_prec_s {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+
+	bhip::Pattern pat;
+	int *browptr_own = nullptr, *bcolind_own = nullptr, *diagind_own = nullptr;
+	bool have_pattern = false;
+
+	const double *vals = nullptr;
+	double *vals_own = nullptr;
+
+	int *posptr = nullptr, *lowerp = nullptr, *upperp = nullptr;
+	long npairs = -1;
+
+	double *iluvals = nullptr, *iluvals2 = nullptr;
+	double *scale = nullptr;
+	bool factored = false, scaled = false;
+	double *ytemp = nullptr;
+	double *dblocks = nullptr;
+	bool jacobi_done = false;
+
+	double *tmp[3] = {nullptr, nullptr, nullptr};    // n-vectors: Jacobi-sync ping-pong
+	double *stage[3] = {nullptr, nullptr, nullptr};  // n-vectors: device copies of host vectors
+	double *red = nullptr;                           // small reduction scratch
+
+	bhip::Timing timing;
+
+	long n() const { return (long)pat.nbrows * pat.bs; }
+	long nvals() const { return (long)pat.nnzb * pat.bs * pat.bs; }
+};

@@ -1,0 +1,220 @@
+// kernels_aux.hip -- integer-only helpers: ILU(0) position lists (compute_ILU_positions_CSR_CSR,
+// src/ilu_pattern.cpp:32-163, with inner_search of src/helper_algorithms.hpp:38-49 and the serial
+// inclusive_scan of src/helper_algorithms.cpp), and the pattern validation the reference only assumes
+// (ascending columns, src/ilu_pattern.cpp:51,67; diagonal block present in every row).
+//
+// The reference builds the lists serially in two passes over all stored entries.  Here each block-row
+// is independent: one thread per row counts (pass 1) and fills (pass 2); the prefix sum in between is a
+// three-phase device scan.  The result is bit-identical to the serial lists: pairs of one entry are
+// emitted in ascending position k exactly as the reference's loop does.
+#include "ctx.hpp"
+
+namespace bhip {
+
+__device__ __forceinline__ int inner_search_dev(const int *aind, int start, int end, int tofind)
+{
+	for (int j = start; j < end; j++)
+		if (aind[j] == tofind)
+			return j;
+	return -1;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void ilu_positions_kernel(const Pattern pat, int *posptr,
+                                                            int *lowerp, int *upperp)
+{
+	const int irow = blockIdx.x * blockDim.x + threadIdx.x;
+	if (irow >= pat.nbrows)
+		return;
+	const int rbeg = pat.browptr[irow], rend = pat.browptr[irow + 1];
+	for (int j = rbeg; j < rend; j++) {
+		const int colj = pat.bcolind[j];
+		const int klimit = (irow > colj) ? colj : irow;
+		int cnt = 0;
+		const int base = FILL ? posptr[j] : 0;
+		for (int k = rbeg; k < rend && pat.bcolind[k] < klimit; k++) {
+			const int krow = pat.bcolind[k];
+			const int ipos = inner_search_dev(pat.bcolind, pat.diagind[krow], pat.browptr[krow + 1], colj);
+			if (ipos > -1) {
+				if (FILL) {
+					lowerp[base + cnt] = k;
+					upperp[base + cnt] = ipos;
+				}
+				cnt++;
+			}
+		}
+		if (!FILL)
+			posptr[j + 1] = cnt;
+	}
+}
+
+// ---- inclusive scan of int32 (three-phase, recursive on the block sums)
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+__global__ __launch_bounds__(256) void scan_tile_kernel(int *data, long n, int *tilesums)
+{
+	__shared__ int wsum[4];
+	const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+	int v[SCAN_ITEMS];
+	int run = 0;
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; q++) {
+		const long idx = base + q;
+		run += (idx < n) ? data[idx] : 0;
+		v[q] = run;
+	}
+	// scan of the per-thread totals: inside the wave, then across the 4 waves
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int incl = run;
+	for (int off = 1; off < 64; off <<= 1) {
+		const int o = __shfl_up(incl, off, 64);
+		if (lane >= off)
+			incl += o;
+	}
+	if (lane == 63)
+		wsum[wave] = incl;
+	__syncthreads();
+	int woff = 0;
+	for (int w = 0; w < wave; w++)
+		woff += wsum[w];
+	const int excl = woff + incl - run;
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; q++) {
+		const long idx = base + q;
+		if (idx < n)
+			data[idx] = v[q] + excl;
+	}
+	if (tilesums && threadIdx.x == 255)
+		tilesums[blockIdx.x] = woff + incl;
+}
+
+__global__ void scan_add_kernel(int *data, long n, const int *tilesums_incl)
+{
+	const long idx = (long)blockIdx.x * 256 + threadIdx.x + SCAN_TILE;  // tile 0 needs no offset
+	if (idx < n)
+		data[idx] += tilesums_incl[idx / SCAN_TILE - 1];
+}
+
+static void inclusive_scan_device(int *data, long n, hipStream_t s)
+{
+	if (n <= 0)
+		return;
+	const long ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+	if (ntiles == 1) {
+		hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(256), 0, s, data, n, (int *)nullptr);
+		BHIP_CHECK(hipGetLastError());
+		return;
+	}
+	int *sums = nullptr;
+	BHIP_CHECK(hipMalloc(&sums, sizeof(int) * ntiles));
+	try {
+		hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, data, n, sums);
+		BHIP_CHECK(hipGetLastError());
+		inclusive_scan_device(sums, ntiles, s);
+		const long rest = n - SCAN_TILE;
+		hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, data, n,
+		                   sums);
+		BHIP_CHECK(hipGetLastError());
+		BHIP_CHECK(hipStreamSynchronize(s));
+	} catch (...) {
+		(void)hipFree(sums);
+		throw;
+	}
+	BHIP_CHECK(hipFree(sums));
+}
+
+long run_ilu_positions(const Pattern &pat, int **posptr_out, int **lowerp_out, int **upperp_out,
+                       hipStream_t s)
+{
+	int *posptr = nullptr, *lowerp = nullptr, *upperp = nullptr;
+	const long nent = pat.nnzb;
+	BHIP_CHECK(hipMalloc(&posptr, sizeof(int) * (nent + 1)));
+	try {
+		BHIP_CHECK(hipMemsetAsync(posptr, 0, sizeof(int) * (nent + 1), s));
+		const unsigned grid = (unsigned)((pat.nbrows + 255) / 256);
+		if (grid) {
+			hipLaunchKernelGGL(ilu_positions_kernel<false>, dim3(grid), dim3(256), 0, s, pat, posptr,
+			                   (int *)nullptr, (int *)nullptr);
+			BHIP_CHECK(hipGetLastError());
+		}
+		inclusive_scan_device(posptr, nent + 1, s);
+		int total = 0;
+		BHIP_CHECK(hipMemcpyAsync(&total, posptr + nent, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+		if (total < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "ILU position list overflows the int32 index type");
+		BHIP_CHECK(hipMalloc(&lowerp, sizeof(int) * (total > 0 ? total : 1)));
+		BHIP_CHECK(hipMalloc(&upperp, sizeof(int) * (total > 0 ? total : 1)));
+		if (grid && total > 0) {
+			hipLaunchKernelGGL(ilu_positions_kernel<true>, dim3(grid), dim3(256), 0, s, pat, posptr,
+			                   lowerp, upperp);
+			BHIP_CHECK(hipGetLastError());
+		}
+		*posptr_out = posptr;
+		*lowerp_out = lowerp;
+		*upperp_out = upperp;
+		return total;
+	} catch (...) {
+		(void)hipFree(posptr);
+		(void)hipFree(lowerp);
+		(void)hipFree(upperp);
+		throw;
+	}
+}
+
+// flags: 1 = unsorted/duplicate columns, 2 = diagind does not point at the diagonal block,
+//        4 = column index out of range, 8 = browptr not monotone or wrong total
+__global__ void validate_kernel(const Pattern pat, int *flags)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= pat.nbrows)
+		return;
+	int f = 0;
+	const int b = pat.browptr[i], e = pat.browptr[i + 1];
+	if (b > e || b < 0 || e > pat.nnzb)
+		f |= 8;
+	else {
+		if (i == 0 && b != 0)
+			f |= 8;
+		if (i == pat.nbrows - 1 && e != pat.nnzb)
+			f |= 8;
+		for (int j = b; j < e; j++) {
+			const int c = pat.bcolind[j];
+			if (c < 0 || c >= pat.nbrows)
+				f |= 4;
+			if (j > b && pat.bcolind[j - 1] >= c)
+				f |= 1;
+		}
+		const int d = pat.diagind[i];
+		if (d < b || d >= e || pat.bcolind[d] != i)
+			f |= 2;
+	}
+	if (f)
+		atomicOr(flags, f);
+}
+
+int validate_pattern_device(const Pattern &pat, hipStream_t s)
+{
+	int *flags = nullptr;
+	BHIP_CHECK(hipMalloc(&flags, sizeof(int)));
+	int h = 0;
+	try {
+		BHIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
+		const unsigned grid = (unsigned)((pat.nbrows + 255) / 256);
+		if (grid) {
+			hipLaunchKernelGGL(validate_kernel, dim3(grid), dim3(256), 0, s, pat, flags);
+			BHIP_CHECK(hipGetLastError());
+		}
+		BHIP_CHECK(hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+	} catch (...) {
+		(void)hipFree(flags);
+		throw;
+	}
+	BHIP_CHECK(hipFree(flags));
+	return h;
+}
+
+}  // namespace bhip

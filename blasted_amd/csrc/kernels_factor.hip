@@ -1,0 +1,511 @@
+// kernels_factor.hip -- asynchronous (block-)ILU(0) factorisation sweeps and the small dense block
+// work around them.
+//
+//   async_block_ilu0_factorize   kernels_ilu0_factorize.hpp:71-98    factor_sweep_kernel (bs>1)
+//   async_ilu0_factorize_kernel  kernels_ilu0_factorize.hpp:19-53    factor_sweep_kernel (bs==1)
+//   diagonal-block inversion     async_blockilu_factor.cpp:143-146   invert_blocks_kernel
+//   BJacobi/Jacobi compute       solverops_jacobi.cpp:43-45,141-147  invert_blocks_kernel
+//   fact_init_{original,sgs}     async_blockilu_factor.cpp:63-93,206-254, async_ilu_factor.cpp:109-151
+//   getScalingVector             rawsrmatrixutils.cpp:343-350
+//   block/scalar_ilu0_nonlinear_res  async_blockilu_factor.cpp:256-297, async_ilu_factor.cpp:179-217
+//   diagonal_dominance           matrix_properties.cpp:10-77
+//
+// Mapping: SUB = BSP*BSP lanes (BSP = bs rounded up to a power of two) own one block-row and walk
+// its stored blocks; lane (r,c) holds entry (r,c) of the current block.  The bs x bs x bs products
+// L_ik U_kj and S U_jj^-1 and the on-the-fly inverse of U_jj are done with wavefront shuffles between
+// the lanes of the group: no LDS allocation, no partial result ever leaves registers, and every entry
+// of iluvals is stored exactly once per sweep (kernels_ilu0_factorize.hpp:34-40).
+#include "ctx.hpp"
+
+namespace bhip {
+
+template <int BS>
+struct FGeo {
+	static constexpr int BSP = BS <= 1 ? 1 : (BS <= 2 ? 2 : (BS <= 4 ? 4 : 8));
+	static constexpr int SUB = BSP * BSP;
+	static constexpr int RPW = 64 / SUB;
+	static constexpr int RPB = 4 * RPW;
+};
+
+__device__ __forceinline__ unsigned xcd_chunk_f(unsigned bid, unsigned nwg)
+{
+	const unsigned xcd = bid & 7u, local = bid >> 3;
+	const unsigned base = nwg >> 3, rem = nwg & 7u;
+	return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+
+// Lane (r,c) of a group holds a(r,c) of a BS x BS matrix (lanes with r>=BS or c>=BS hold anything).
+// Returns inverse(r,c) in lane (r,c).  n<=4: adjugate / determinant (the closed form Eigen's
+// fixed-size inverse() uses); larger: Gauss-Jordan with partial pivoting on the identity-padded
+// BSP x BSP matrix.
+template <int BS, int BSP>
+__device__ __forceinline__ double group_inverse(const double a, const int gbase, const int r, const int c)
+{
+	if (BS == 1)
+		return 1.0 / a;
+	if (BS == 2) {
+		const double a00 = __shfl(a, gbase + 0, 64), a10 = __shfl(a, gbase + 1, 64);
+		const double a01 = __shfl(a, gbase + BSP, 64), a11 = __shfl(a, gbase + BSP + 1, 64);
+		const double invdet = 1.0 / (a00 * a11 - a01 * a10);
+		const double adj = (r == 0 && c == 0) ? a11 : (r == 1 && c == 1) ? a00 : (r == 0 ? -a01 : -a10);
+		return adj * invdet;
+	}
+	if (BS == 3 || BS == 4) {
+		// this lane computes cofactor C(c,r): delete row c and column r
+		const int rr = r < BS ? r : 0, cc = c < BS ? c : 0;
+		double M[3][3];
+#pragma unroll
+		for (int x = 0; x < BS - 1; x++)
+#pragma unroll
+			for (int y = 0; y < BS - 1; y++) {
+				const int ri = x + (x >= cc ? 1 : 0);  // x-th row of {0..BS-1} \ {cc}
+				const int ci = y + (y >= rr ? 1 : 0);  // y-th column of {0..BS-1} \ {rr}
+				M[x][y] = __shfl(a, gbase + ri + ci * BSP, 64);
+			}
+		double minor;
+		if (BS == 3)
+			minor = M[0][0] * M[1][1] - M[0][1] * M[1][0];
+		else
+			minor = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) -
+			        M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+			        M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+		const double cof = ((rr + cc) & 1) ? -minor : minor;  // = C(cc, rr)
+		// det = sum_q a(0,q) C(0,q); C(0,q) lives in lane (r=q, c=0)
+		double det = 0.0;
+#pragma unroll
+		for (int q = 0; q < BS; q++)
+			det += __shfl(a, gbase + 0 + q * BSP, 64) * __shfl(cof, gbase + q, 64);
+		return cof * (1.0 / det);
+	}
+	// Gauss-Jordan, partial pivoting
+	double m = (r < BS && c < BS) ? a : (r == c ? 1.0 : 0.0);
+	double inv = (r == c) ? 1.0 : 0.0;
+#pragma unroll 1
+	for (int k = 0; k < BS; k++) {
+		int p = k;
+		double best = fabs(__shfl(m, gbase + k + k * BSP, 64));
+		for (int q = k + 1; q < BS; q++) {
+			const double v = fabs(__shfl(m, gbase + q + k * BSP, 64));
+			if (v > best) {
+				best = v;
+				p = q;
+			}
+		}
+		// swap rows k and p
+		const int srcrow = (r == k) ? p : (r == p ? k : r);
+		m = __shfl(m, gbase + srcrow + c * BSP, 64);
+		inv = __shfl(inv, gbase + srcrow + c * BSP, 64);
+		const double piv = 1.0 / __shfl(m, gbase + k + k * BSP, 64);
+		const double mk = __shfl(m, gbase + k + c * BSP, 64) * piv;     // row k, my column
+		const double ik = __shfl(inv, gbase + k + c * BSP, 64) * piv;
+		const double f = __shfl(m, gbase + r + k * BSP, 64);            // my row, column k
+		if (r == k) {
+			m = mk;
+			inv = ik;
+		} else {
+			m -= f * mk;
+			inv -= f * ik;
+		}
+	}
+	return inv;
+}
+
+// out(r,c) = sum_m x(r,m) y(m,c) with x, y distributed one entry per lane
+template <int BS, int BSP>
+__device__ __forceinline__ double group_gemm(const double x, const double y, const int gbase,
+                                             const int r, const int c)
+{
+	double s = 0.0;
+#pragma unroll
+	for (int m = 0; m < BS; m++)
+		s += __shfl(x, gbase + r + m * BSP, 64) * __shfl(y, gbase + m + c * BSP, 64);
+	return s;
+}
+
+template <int BS, bool RM, bool RESID>
+__global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, double *resid_partial)
+{
+	using Ge = FGeo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / SUB, u = lane % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(SUB - 1);
+
+	const unsigned chunk = xcd_chunk_f(blockIdx.x, gridDim.x);
+	const long rowlin = (long)chunk * Ge::RPB + wave * Ge::RPW + g;
+	const bool rowok = rowlin < a.pat.nbrows;
+	const int irow = rowok ? (int)rowlin : 0;
+	int jbeg = 0, jend = 0;
+	if (rowok) {
+		jbeg = a.pat.browptr[irow];
+		jend = a.pat.browptr[irow + 1];
+	}
+	double resid = 0.0;
+
+	for (int jpos = jbeg; jpos < jend; jpos++) {
+		const int col = a.pat.bcolind[jpos];
+		double s = active ? a.avals[(long)jpos * BS2 + e] : 0.0;
+		if (a.scale && active) {
+			if (BS == 1) {
+				s *= a.scale[irow];
+				s *= a.scale[col];
+			} else
+				s *= a.scale[(long)irow * BS + r] * a.scale[(long)col * BS + c];
+		}
+		const int kbeg = a.posptr[jpos], kend = a.posptr[jpos + 1];
+		for (int k = kbeg; k < kend; k++) {
+			const double lv = active ? a.in[(long)a.lowerp[k] * BS2 + e] : 0.0;
+			const double uv = active ? a.in[(long)a.upperp[k] * BS2 + e] : 0.0;
+			if (BS == 1)
+				s -= lv * uv;
+			else
+				s -= group_gemm<BS, BSP>(lv, uv, gbase, r, c);
+		}
+		if (RESID) {
+			// A - LU on the pattern, async_blockilu_factor.cpp:278-288
+			const double cur = active ? a.in[(long)jpos * BS2 + e] : 0.0;
+			if (irow > col) {
+				const double dv = active ? a.in[(long)a.pat.diagind[col] * BS2 + e] : 0.0;
+				s -= (BS == 1) ? cur * dv : group_gemm<BS, BSP>(cur, dv, gbase, r, c);
+			} else
+				s -= cur;
+			if (active)
+				resid += fabs(s);
+		} else if (irow > col) {
+			const double dv = active ? a.in[(long)a.pat.diagind[col] * BS2 + e] : 0.0;
+			double res;
+			if (BS == 1)
+				res = s / dv;
+			else {
+				const double inv = group_inverse<BS, BSP>(dv, gbase, r, c);
+				res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
+			}
+			if (active)
+				a.out[(long)jpos * BS2 + e] = res;
+		} else if (active)
+			a.out[(long)jpos * BS2 + e] = s;
+	}
+
+	if (RESID) {
+		// one partial per workgroup, summed on the host side in fixed order
+		__shared__ double wsum[4];
+		for (int off = 32; off > 0; off >>= 1)
+			resid += __shfl_xor(resid, off, 64);
+		if (lane == 0)
+			wsum[wave] = resid;
+		__syncthreads();
+		if (threadIdx.x == 0)
+			resid_partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+	}
+}
+
+// dst block = inverse(src block); blocks addressed by row or through diagind
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void invert_blocks_kernel(const Pattern pat, const double *src,
+                                                            const int src_by_diag, double *dst,
+                                                            const int dst_by_diag)
+{
+	using Ge = FGeo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / SUB, u = lane % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(SUB - 1);
+	const long rowlin = (long)blockIdx.x * Ge::RPB + wave * Ge::RPW + g;
+	const bool rowok = rowlin < pat.nbrows;
+	const int i = rowok ? (int)rowlin : 0;
+	const long dgpos = rowok ? pat.diagind[i] : 0;
+	const long sblk = src_by_diag ? dgpos : i, dblk = dst_by_diag ? dgpos : i;
+	const double av = (rowok && active) ? src[sblk * BS2 + e] : ((r == c) ? 1.0 : 0.0);
+	const double inv = group_inverse<BS, BSP>(av, gbase, r, c);
+	if (rowok && active)
+		dst[dblk * BS2 + e] = inv;
+}
+
+// INIT_F_ORIGINAL with scaling / INIT_F_SGS first pass: ilu = scaled A
+template <int BS, bool RM>
+__global__ void scaled_copy_kernel(const Pattern pat, const double *avals, const double *scale,
+                                   double *ilu)
+{
+	constexpr int BS2 = BS * BS;
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const long nv = (long)pat.nnzb * BS2;
+	if (idx >= nv)
+		return;
+	const long jpos = idx / BS2;
+	const int e = (int)(idx % BS2);
+	const int r = RM ? e / BS : e % BS, c = RM ? e % BS : e / BS;
+	// row of jpos: binary search in browptr
+	int lo = 0, hi = pat.nbrows;
+	while (hi - lo > 1) {
+		const int mid = (lo + hi) >> 1;
+		if (pat.browptr[mid] <= jpos)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const int irow = lo, col = pat.bcolind[jpos];
+	double v = avals[idx];
+	if (scale) {
+		if (BS == 1)
+			v = scale[irow] * v * scale[col];
+		else
+			v *= scale[(long)irow * BS + r] * scale[(long)col * BS + c];
+	}
+	ilu[idx] = v;
+}
+
+// INIT_F_SGS second pass: strictly lower blocks right-multiplied by D_col^-1
+// (dinv: inverses of the (scaled) diagonal blocks, indexed by block-row)
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void sgs_init_lower_kernel(const Pattern pat, const double *dinv,
+                                                             double *ilu)
+{
+	using Ge = FGeo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / SUB, u = lane % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(SUB - 1);
+	const long rowlin = (long)blockIdx.x * Ge::RPB + wave * Ge::RPW + g;
+	const bool rowok = rowlin < pat.nbrows;
+	const int i = rowok ? (int)rowlin : 0;
+	int jbeg = 0, jend = 0;
+	if (rowok) {
+		jbeg = pat.browptr[i];
+		jend = pat.diagind[i];
+	}
+	for (int j = jbeg; j < jend; j++) {
+		const int col = pat.bcolind[j];
+		const double lv = active ? ilu[(long)j * BS2 + e] : 0.0;
+		const double dv = active ? dinv[(long)col * BS2 + e] : 0.0;
+		const double res = (BS == 1) ? lv * dv : group_gemm<BS, BSP>(lv, dv, gbase, r, c);
+		if (active)
+			ilu[(long)j * BS2 + e] = res;
+	}
+}
+
+__global__ void scaling_vector_kernel(const Pattern pat, const double *vals, double *scale)
+{
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int bs = pat.bs;
+	if (idx >= (long)pat.nbrows * bs)
+		return;
+	const int i = (int)(idx / bs), j = (int)(idx % bs);
+	scale[idx] = 1.0 / sqrt(vals[(long)pat.diagind[i] * bs * bs + j * bs + j]);
+}
+
+__global__ void mul_inplace_kernel(double *z, const double *s, long n)
+{
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < n)
+		z[idx] *= s[idx];
+}
+
+// per-row diagonal dominance terms (matrix_properties.cpp:19-66): writes 4 doubles per workgroup
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void diag_dominance_kernel(const Pattern pat, const double *fv,
+                                                             double *partial)
+{
+	constexpr int BS2 = BS * BS;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	double lavg = 0, lmin = 1e30, uavg = 0, umin = 1e30;
+	if (i < pat.nbrows) {
+		const int dg = pat.diagind[i];
+		for (int rr = 0; rr < BS; rr++) {
+			double du = 0, dl = 0;
+			for (int cc = 0; cc < BS; cc++)
+				if (cc != rr)
+					du += fabs(fv[(long)dg * BS2 + (RM ? rr * BS + cc : cc * BS + rr)]);
+			for (int jj = dg + 1; jj < pat.browptr[i + 1]; jj++)
+				for (int cc = 0; cc < BS; cc++)
+					du += fabs(fv[(long)jj * BS2 + (RM ? rr * BS + cc : cc * BS + rr)]);
+			for (int jj = pat.browptr[i]; jj < dg; jj++)
+				for (int cc = 0; cc < BS; cc++)
+					dl += fabs(fv[(long)jj * BS2 + (RM ? rr * BS + cc : cc * BS + rr)]);
+			dl = 1.0 - dl;
+			du = 1.0 - du / fabs(fv[(long)dg * BS2 + rr * BS + rr]);
+			lavg += dl;
+			uavg += du;
+			lmin = fmin(lmin, dl);
+			umin = fmin(umin, du);
+		}
+	}
+	__shared__ double sh[4][256];
+	sh[0][threadIdx.x] = lavg;
+	sh[1][threadIdx.x] = lmin;
+	sh[2][threadIdx.x] = uavg;
+	sh[3][threadIdx.x] = umin;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if (threadIdx.x < off) {
+			sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+			sh[1][threadIdx.x] = fmin(sh[1][threadIdx.x], sh[1][threadIdx.x + off]);
+			sh[2][threadIdx.x] += sh[2][threadIdx.x + off];
+			sh[3][threadIdx.x] = fmin(sh[3][threadIdx.x], sh[3][threadIdx.x + off]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		for (int q = 0; q < 4; q++)
+			partial[(long)blockIdx.x * 4 + q] = sh[q][0];
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+
+#define BHIP_BS_SWITCH(BSVAL, RMVAL, CALL)                                       \
+	switch (BSVAL) {                                                             \
+	case 1: { constexpr int BS = 1; constexpr bool RM = false; CALL; } break;    \
+	case 2: if (RMVAL) { constexpr int BS = 2; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 2; constexpr bool RM = false; CALL; } break; \
+	case 3: if (RMVAL) { constexpr int BS = 3; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 3; constexpr bool RM = false; CALL; } break; \
+	case 4: if (RMVAL) { constexpr int BS = 4; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 4; constexpr bool RM = false; CALL; } break; \
+	case 5: if (RMVAL) { constexpr int BS = 5; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 5; constexpr bool RM = false; CALL; } break; \
+	case 7: if (RMVAL) { constexpr int BS = 7; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 7; constexpr bool RM = false; CALL; } break; \
+	case 8: if (RMVAL) { constexpr int BS = 8; constexpr bool RM = true; CALL; } \
+	        else { constexpr int BS = 8; constexpr bool RM = false; CALL; } break; \
+	default: BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "block size not instantiated (1,2,3,4,5,7,8)"); \
+	}
+
+void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
+{
+	if (a.pat.nbrows == 0)
+		return;
+	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
+		const unsigned grid = (unsigned)(((long)a.pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+		hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, false>), dim3(grid), dim3(256), 0, s, a,
+		                   (double *)nullptr);
+	})
+	BHIP_CHECK(hipGetLastError());
+}
+
+double run_nonlinear_res(const FactorArgs &a, double *dev_scratch, hipStream_t s)
+{
+	if (a.pat.nbrows == 0)
+		return 0.0;
+	unsigned grid = 0;
+	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
+		grid = (unsigned)(((long)a.pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+		hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, true>), dim3(grid), dim3(256), 0, s, a,
+		                   dev_scratch);
+	})
+	BHIP_CHECK(hipGetLastError());
+	std::vector<double> h(grid);
+	BHIP_CHECK(hipMemcpyAsync(h.data(), dev_scratch, sizeof(double) * grid, hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	double sum = 0;
+	for (unsigned i = 0; i < grid; i++)
+		sum += h[i];
+	return sum;
+}
+
+void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_by_diag, double *dst,
+                               long dst_by_diag, hipStream_t s)
+{
+	if (pat.nbrows == 0)
+		return;
+	BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
+		const unsigned grid = (unsigned)(((long)pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+		hipLaunchKernelGGL((invert_blocks_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat, src,
+		                   (int)src_by_diag, dst, (int)dst_by_diag);
+	})
+	BHIP_CHECK(hipGetLastError());
+}
+
+void launch_scaling_vector(const Pattern &pat, const double *vals, double *scale, hipStream_t s)
+{
+	const long n = (long)pat.nbrows * pat.bs;
+	if (n == 0)
+		return;
+	hipLaunchKernelGGL(scaling_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pat,
+	                   vals, scale);
+	BHIP_CHECK(hipGetLastError());
+}
+
+void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	hipLaunchKernelGGL(mul_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, scale, n);
+	BHIP_CHECK(hipGetLastError());
+}
+
+// iluvals initial guess.  dblk_scratch: nbrows*bs*bs doubles, used by INIT_F_SGS only.
+void launch_fact_init(const Pattern &pat, const double *avals, const double *scale, int init_type,
+                      double *iluvals, double *dblk_scratch, hipStream_t s)
+{
+	const long nv = (long)pat.nnzb * pat.bs * pat.bs;
+	if (nv == 0)
+		return;
+	const unsigned egrid = (unsigned)((nv + 255) / 256);
+	auto copy_scaled = [&]() {
+		if (!scale) {
+			BHIP_CHECK(hipMemcpyAsync(iluvals, avals, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+			return;
+		}
+		BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
+			hipLaunchKernelGGL((scaled_copy_kernel<BS, RM>), dim3(egrid), dim3(256), 0, s, pat, avals,
+			                   scale, iluvals);
+		})
+	};
+	switch (init_type) {
+	case BLASTED_HIP_INIT_F_ZERO:
+		BHIP_CHECK(hipMemsetAsync(iluvals, 0, sizeof(double) * nv, s));
+		if (pat.bs > 1)
+			break;
+		// scalar: the reference falls through into INIT_F_ORIGINAL (async_ilu_factor.cpp:48-54)
+		[[fallthrough]];
+	case BLASTED_HIP_INIT_F_ORIGINAL: copy_scaled(); break;
+	case BLASTED_HIP_INIT_F_SGS:
+		copy_scaled();
+		// D^-1 of the (scaled) diagonal, then L <- L D_col^-1
+		launch_invert_diag_blocks(pat, iluvals, 1, dblk_scratch, 0, s);
+		BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
+			const unsigned grid = (unsigned)(((long)pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+			hipLaunchKernelGGL((sgs_init_lower_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat,
+			                   dblk_scratch, iluvals);
+		})
+		break;
+	default: break;  // INIT_F_NONE: keep the contents
+	}
+	BHIP_CHECK(hipGetLastError());
+}
+
+void run_diag_dominance(const Pattern &pat, const double *fvals, double *dev_scratch, double *out4,
+                        hipStream_t s)
+{
+	const unsigned grid = (unsigned)((pat.nbrows + 255) / 256);
+	BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
+		hipLaunchKernelGGL((diag_dominance_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat, fvals,
+		                   dev_scratch);
+	})
+	BHIP_CHECK(hipGetLastError());
+	std::vector<double> h((size_t)grid * 4);
+	BHIP_CHECK(hipMemcpyAsync(h.data(), dev_scratch, sizeof(double) * grid * 4, hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	double lavg = 0, lmin = 1e30, uavg = 0, umin = 1e30;
+	for (unsigned b = 0; b < grid; b++) {
+		lavg += h[b * 4 + 0];
+		lmin = h[b * 4 + 1] < lmin ? h[b * 4 + 1] : lmin;
+		uavg += h[b * 4 + 2];
+		umin = h[b * 4 + 3] < umin ? h[b * 4 + 3] : umin;
+	}
+	const double den = (double)pat.nbrows * pat.bs;
+	out4[0] = lavg / den;
+	out4[1] = lmin;
+	out4[2] = uavg / den;
+	out4[3] = umin;
+}
+
+}  // namespace bhip

@@ -1,0 +1,146 @@
+/* blasted_hip.h -- C ABI of the MI355X (gfx950) backend of BLASTed's preconditioner-apply hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The C++ operator
+ * classes of the host layer (blasted_amd/host: SRPreconditioner hierarchy, SRFactory, PCSHELL glue)
+ * call ONLY these entry points; each one names the reference routine whose OpenMP loop nest it
+ * replaces (paths relative to the BLASTed source tree).
+ *
+ * Object model: one `blasted_hip_prec` per reference operator object (SRPreconditioner instance).
+ * It owns the device mirror of the sparsity pattern (uploaded once), borrows or mirrors the matrix
+ * values (re-set before every compute(), include/solverops_ilu0.hpp:54-56), and owns what the
+ * reference operator owns: iluvals / scale / ytemp (src/solverops_ilu0.cpp:150-183), dblocks
+ * (src/solverops_jacobi.cpp:31-38) and the ILU position lists (include/ilu_pattern.hpp:39-52).
+ * All work is enqueued on the object's HIP stream.  Calls taking host vectors return after the result
+ * is in host memory; calls taking device vectors return once the work is enqueued (stream ordered).
+ *
+ * Storage conventions are the reference's (include/srmatrixdefs.hpp:98-125): browptr[nbrows+1],
+ * bcolind[nnzb] ascending inside every block-row, diagind[nbrows] = storage position of the
+ * diagonal block (present in every block-row), vals[nnzb*bs*bs]; vectors block-interleaved.
+ * FP64 values, int32 indices (the reference instantiates <double,int> only).
+ *
+ * Every function returns BLASTED_HIP_OK or an error code; blasted_hip_last_error() gives the text.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry point fails.
+ */
+#ifndef BLASTED_HIP_H
+#define BLASTED_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blasted_hip_prec_s *blasted_hip_prec;
+
+enum {
+	BLASTED_HIP_OK = 0,
+	BLASTED_HIP_EINVAL = 1,   /* invalid argument (std::invalid_argument in the host layer)      */
+	BLASTED_HIP_ENODEV = 2,   /* no usable HIP device                                            */
+	BLASTED_HIP_ERUNTIME = 3, /* a HIP call failed (std::runtime_error with hipGetErrorString)   */
+	BLASTED_HIP_ESTATE = 4,   /* call order violated (e.g. apply before factorize)               */
+	BLASTED_HIP_ENOTIMPL = 5  /* block size / layout not instantiated                            */
+};
+
+/* in-block layout: Eigen::ColMajor / Eigen::RowMajor of include/blasted_config.hpp:27-28 */
+enum { BLASTED_HIP_COLMAJOR = 0, BLASTED_HIP_ROWMAJOR = 1 };
+
+/* where a caller's array lives */
+enum { BLASTED_HIP_HOST = 0, BLASTED_HIP_DEVICE = 1 };
+
+/* sweep semantics.  ASYNC: in-place chaotic sweeps, one launch per sweep (the GPU counterpart of the
+ * reference's `omp for schedule(dynamic) nowait`, src/solverops_ilu0.cpp:99-108).  JACOBI_SYNC:
+ * double-buffered synchronous Jacobi sweeps, deterministic; used by the parity tests. */
+enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1 };
+
+/* include/async_initialization_decl.hpp:15-34, same numeric values as FactInit / ApplyInit */
+enum { BLASTED_HIP_INIT_F_ZERO = 0, BLASTED_HIP_INIT_F_ORIGINAL = 1, BLASTED_HIP_INIT_F_SGS = 2,
+       BLASTED_HIP_INIT_F_NONE = 3 };
+enum { BLASTED_HIP_INIT_A_ZERO = 0, BLASTED_HIP_INIT_A_JACOBI = 1, BLASTED_HIP_INIT_A_NONE = 2 };
+
+const char *blasted_hip_last_error(void);
+int blasted_hip_device_count(void);
+
+/* Lifetime.  stream: a hipStream_t, or NULL to let the object create its own.
+ * Replaces: construction/destruction of an SRPreconditioner (src/solverops_base.cpp:20-24). */
+int blasted_hip_create(blasted_hip_prec *out, int device, void *stream);
+int blasted_hip_destroy(blasted_hip_prec p);
+int blasted_hip_synchronize(blasted_hip_prec p);
+
+/* Sparsity pattern, once per object.  Validates sorted columns and the diagonal positions.
+ * bs: 1 (scalar CSR semantics of AsyncILU0/AsyncSGS/Jacobi) or one of the instantiated block sizes.
+ * Replaces: the SRMatrixStorage/CRawBSRMatrix view held by SRPreconditioner
+ * (include/solverops_base.hpp:67-78). */
+int blasted_hip_set_pattern(blasted_hip_prec p, int nbrows, int nnzb, int bs, int layout,
+                            const int *browptr, const int *bcolind, const int *diagind, int loc);
+
+/* Matrix values, before every compute.  loc == DEVICE borrows the pointer (zero copy; it must stay
+ * valid and unchanged until the next set_values); loc == HOST uploads into an owned mirror. */
+int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc);
+
+/* ---- ILU(0) ------------------------------------------------------------------------------ */
+
+/* compute_ILU_positions_CSR_CSR, src/ilu_pattern.cpp:32-163 (integer work; bit-exact). */
+int blasted_hip_ilu0_positions(blasted_hip_prec p);
+/* total number of (lower,upper) pairs, and a host copy of the three lists (tests, diagnostics) */
+int blasted_hip_ilu0_positions_size(blasted_hip_prec p, long *npairs);
+int blasted_hip_ilu0_get_positions(blasted_hip_prec p, int *posptr, int *lowerp, int *upperp);
+
+/* block_ilu0_factorize, src/async_blockilu_factor.cpp:47-149 (bs>1: diagonal blocks left inverted)
+ * scalar_ilu0_factorize, src/async_ilu_factor.cpp:36-98 (bs==1: diagonal not inverted; INIT_F_ZERO
+ * falls through to INIT_F_ORIGINAL as in the reference).
+ * use_scaling: symmetric scaling by getScalingVector, src/rawsrmatrixutils.cpp:343-350.
+ * precinfo: NULL, or 6 doubles in PrecInfo order (include/preconditioner_diagnostics.hpp:14-43). */
+int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_init, int use_scaling,
+                               int mode, double *precinfo);
+
+/* block_ilu0_apply, src/solverops_ilu0.cpp:55-148 ; scalar_ilu0_apply, :239-321.
+ * z = S U^-1 L^-1 S r by napplysweeps lower sweeps then napplysweeps upper sweeps.
+ * apply_init other than ZERO / JACOBI -> BLASTED_HIP_EINVAL (the reference throws, :125-126). */
+int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
+                           int apply_init, int mode, int loc);
+
+/* ---- (block-)Jacobi, SGS, relaxation ----------------------------------------------------- */
+
+/* BJacobiSRPreconditioner::compute / JacobiSRPreconditioner::compute,
+ * src/solverops_jacobi.cpp:31-48,150-162: dblocks_i = A_ii^-1. */
+int blasted_hip_jacobi_compute(blasted_hip_prec p);
+/* BJacobiSRPreconditioner::apply, src/solverops_jacobi.cpp:51-63 */
+int blasted_hip_jacobi_apply(blasted_hip_prec p, const double *r, double *z, int loc);
+
+/* Async[Block]SGS_SRPreconditioner::apply, src/solverops_sgs.cpp:47-83,149-176.
+ * With INIT_A_NONE z is read as the initial guess of the backward sweeps (as in the reference). */
+int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
+                          int apply_init, int mode, int loc);
+/* Async[Block]SGS_SRPreconditioner::apply_relax, src/solverops_sgs.cpp:85-116,178-203:
+ * maxits x (ascending pass, descending pass) of x_i = D_i^-1 (b_i - sum_{j!=i} A_ij x_j); x in/out. */
+int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int mode,
+                          int loc);
+
+/* ---- SpMV --------------------------------------------------------------------------------- */
+
+/* BLAS_BSR::matrix_apply / BLAS_CSR::matrix_apply, src/blas/matvecs.cpp:26-48,78-92: y = A x */
+int blasted_hip_spmv(blasted_hip_prec p, const double *x, double *y, int loc);
+/* BLAS_BSR::gemv3 / BLAS_CSR::gemv3, src/blas/matvecs.cpp:52-75,94-108: z = a A x + b y
+ * (x must not alias z) */
+int blasted_hip_gemv3(blasted_hip_prec p, double a, const double *x, double b, const double *y,
+                      double *z, int loc);
+
+/* ---- read-back of operator state (tests, -blasted_compute_preconditioner_info) ------------ */
+int blasted_hip_get_iluvals(blasted_hip_prec p, double *out_host);  /* nnzb*bs*bs */
+int blasted_hip_get_dblocks(blasted_hip_prec p, double *out_host);  /* nbrows*bs*bs */
+int blasted_hip_get_scale(blasted_hip_prec p, double *out_host);    /* nbrows*bs */
+int blasted_hip_get_ytemp(blasted_hip_prec p, double *out_host);    /* nbrows*bs */
+/* device pointer of the factor storage (benchmarks: initialise in HBM without a host copy) */
+int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr);
+
+/* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */
+/* When enabled every apply/relax/spmv/factor call brackets its sweep kernels with hipEvents on the
+ * object's stream; nothing is synchronised until blasted_hip_get_timing.
+ * out[0..5] = {lower-sweep ms, lower launches, upper-sweep ms, upper launches, other ms, other launches}
+ * ("lower" = ascending sweep kernel, "upper" = descending sweep kernel; for SpMV and the
+ * factorisation sweeps the time is reported under "lower"). */
+int blasted_hip_set_timing(blasted_hip_prec p, int enable);
+int blasted_hip_get_timing(blasted_hip_prec p, double *out6, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

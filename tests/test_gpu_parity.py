@@ -1,0 +1,398 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical
+inputs.  Tiers:
+  P0  integer structures bit-exact;
+  P2  HIP JACOBI_SYNC == oracle JACOBI_SYNC at the same sweep counts, rel <= 1e-12;
+  P3  HIP ASYNC run to convergence == oracle exact (serial) result, rel <= 1e-10
+      (the north-star's "FP within 1e-10 rel for the Poisson-FD case");
+plus the reference's known-answer fixtures run on the GPU.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from blasted_amd import capi, mtxio, workloads as W
+from krylov import bicgstab
+
+pytestmark = pytest.mark.gpu
+
+TOL_SYNC = 1e-12
+TOL_EXACT = 1e-10
+DBL_EPS = np.finfo(np.float64).eps
+
+
+def G(golden, name):
+    return os.path.join(golden, name)
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_prec(m):
+    p = capi.Prec(0)
+    p.set_matrix(m)
+    return p
+
+
+def matrices(golden):
+    return {
+        "2dcyl1_bs4_col": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False),
+        "2dcyl1_bs4_row": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, True),
+        "2dcyl1_csr": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 1),
+        "msc_csr": lambda: mtxio.read_mtx_bsr(G(golden, "msc00726.mtx"), 1),
+        "poisson16_csr": lambda: W.poisson3d(16, 1),
+        "poisson16_bs4": lambda: W.poisson3d(16, 4),
+        "poisson11_bs4_row": lambda: W.poisson3d(11, 4, rowmajor=True),
+        "poisson12_bs5": lambda: W.poisson3d(12, 5),
+        "poisson9_bs8": lambda: W.poisson3d(9, 8),
+        "poisson8_bs3": lambda: W.poisson3d(8, 3),
+        "poisson8_bs7_row": lambda: W.poisson3d(8, 7, rowmajor=True),
+        "poisson8_bs2": lambda: W.poisson3d(8, 2),
+        "random_bs5": lambda: W.random_bsr(1500, 5, avg_offdiag=8, seed=12345),
+        "random_bs4": lambda: W.random_bsr(777, 4, avg_offdiag=5, seed=7),
+        "random_csr": lambda: W.random_bsr(1001, 1, avg_offdiag=6, seed=11),
+    }
+
+
+ALL = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16_csr", "poisson16_bs4",
+       "poisson11_bs4_row", "poisson12_bs5", "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row",
+       "poisson8_bs2", "random_bs5", "random_bs4", "random_csr"]
+
+
+# ---------------------------------------------------------------------------- P0 integer structures
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "msc_csr", "poisson16_csr", "random_bs5", "random_csr"])
+def test_ilu_positions_bit_exact(golden, case):
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    got = p.ilu0_positions()
+    want = O.ilu_positions(m)
+    for g, w in zip(got, want):
+        assert g.dtype == np.int32 and np.array_equal(g, w)
+    p.close()
+
+
+def test_invalid_patterns_are_rejected():
+    m = W.poisson3d(6, 4)
+    bad = dict(m)
+    bc = m["bcolind"].copy()
+    bc[[0, 1]] = bc[[1, 0]]  # unsorted columns in row 0
+    bad["bcolind"] = bc
+    p = capi.Prec(0)
+    with pytest.raises(capi.BlastedHipError) as ei:
+        p.set_matrix(bad)
+    assert ei.value.code == capi.EINVAL
+    bad = dict(m)
+    dg = m["diagind"].copy()
+    dg[3] += 1
+    bad["diagind"] = dg
+    p2 = capi.Prec(0)
+    with pytest.raises(capi.BlastedHipError):
+        p2.set_matrix(bad)
+    bad = dict(m)
+    bad["bs"] = 6
+    p3 = capi.Prec(0)
+    with pytest.raises(capi.BlastedHipError) as ei:
+        p3.set_matrix(bad)
+    assert ei.value.code == capi.ENOTIMPL
+
+
+# ---------------------------------------------------------------------------- SpMV (K11)
+
+@pytest.mark.parametrize("bs,rowmajor", [(1, False), (7, True), (7, False)])
+def test_spmv_dk01r_known_answer(golden, bs, rowmajor):
+    m = mtxio.read_mtx_bsr(G(golden, "DK01R.mtx"), bs, rowmajor)
+    x = mtxio.read_mtx_dense(G(golden, "DK01R_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "DK01R_b.mtx"))
+    p = make_prec(m)
+    y = p.spmv(x)
+    assert np.all(np.abs(y - b) < 10 * DBL_EPS)  # tests/mat_ops/testbsrmatrix.cpp:46-48
+    assert rel(y, O.spmv(m, x)) < 1e-13 or np.abs(y - O.spmv(m, x)).max() < 1e-14
+    p.close()
+
+
+@pytest.mark.parametrize("rowmajor", [False, True])
+def test_spmv_small_block3_known_answer(golden, rowmajor):
+    m = mtxio.read_mtx_bsr(G(golden, "small_block3_matrix.mtx"), 3, rowmajor)
+    x = mtxio.read_mtx_dense(G(golden, "small_block3_matrix_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "small_block3_matrix_b.mtx"))
+    p = make_prec(m)
+    assert np.all(np.abs(p.spmv(x) - b) < 10 * DBL_EPS)
+    p.close()
+
+
+@pytest.mark.parametrize("case", ALL)
+def test_spmv_gemv3_vs_oracle(golden, case):
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    x = W.rhs_vector(n)
+    y = np.cos(0.11 * np.arange(n))
+    p = make_prec(m)
+    assert rel(p.spmv(x), O.spmv(m, x)) < 1e-13
+    assert rel(p.gemv3(-1.5, x, 0.25, y), O.gemv3(m, -1.5, x, 0.25, y)) < 1e-13
+    p.close()
+
+
+def test_spmv_2dcyl1_residual(golden):
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4)
+    x = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
+    b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
+    p = make_prec(m)
+    assert np.linalg.norm(p.spmv(x) - b) < 1e-12
+    p.close()
+
+
+# ---------------------------------------------------------------------------- ILU(0) factorisation
+
+@pytest.mark.parametrize("case", ALL)
+@pytest.mark.parametrize("init", [capi.INIT_F_ORIGINAL, capi.INIT_F_SGS])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_ilu_factor_sync_sweeps_match_oracle(golden, case, init, usescale):
+    m = matrices(golden)[case]()
+    if usescale and case.startswith("random"):
+        pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
+    p = make_prec(m)
+    for sweeps in (1, 3):
+        p.ilu0_factorize(sweeps, init=init, usescale=usescale, mode=capi.JACOBI_SYNC)
+        want = O.ilu0_factorize(m, None, sweeps, mode=O.JACOBI_SYNC, init=init, usescale=usescale)
+        assert rel(p.get_iluvals(), want["iluvals"]) < TOL_SYNC
+        if usescale:
+            assert rel(p.get_scale(), want["scale"]) < 1e-15
+    p.close()
+
+
+@pytest.mark.parametrize("case", ALL)
+def test_ilu_factor_async_converges_to_exact(golden, case):
+    m = matrices(golden)[case]()
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL, compute_info=True)
+    p = make_prec(m)
+    nsw = 90
+    info = p.ilu0_factorize(nsw, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC, compute_info=True)
+    assert rel(p.get_iluvals(), exact["iluvals"]) < TOL_EXACT
+    # -blasted_compute_preconditioner_info, tests/testutils.cpp:297-308
+    assert info[1] > 0 and info[0] / info[1] < 1e-12
+    assert rel(info[1:2], exact["precinfo"][1:2]) < 1e-12          # initial remainder: same input
+    assert np.abs(info[2:] - exact["precinfo"][2:]).max() < 1e-8   # diagonal dominance of the factors
+    p.close()
+
+
+def test_scalar_zero_init_falls_through(golden):
+    """async_ilu_factor.cpp:48-54: for bs==1 INIT_F_ZERO behaves as INIT_F_ORIGINAL."""
+    m = matrices(golden)["msc_csr"]()
+    p = make_prec(m)
+    p.ilu0_factorize(0, init=capi.INIT_F_ZERO)
+    assert np.array_equal(p.get_iluvals(), m["vals"])
+    p.close()
+
+
+def test_warm_start_init_none(golden):
+    m = matrices(golden)["poisson16_csr"]()
+    p = make_prec(m)
+    p.ilu0_factorize(2, init=capi.INIT_F_ORIGINAL, mode=capi.JACOBI_SYNC)
+    p.ilu0_factorize(3, init=capi.INIT_F_NONE, mode=capi.JACOBI_SYNC)
+    want = O.ilu0_factorize(m, None, 5, mode=O.JACOBI_SYNC, init=O.INIT_F_ORIGINAL)["iluvals"]
+    assert rel(p.get_iluvals(), want) < TOL_SYNC
+    p.close()
+
+
+# ---------------------------------------------------------------------------- ILU(0) apply (the metric's kernel)
+
+def exact_factor(m, usescale=False):
+    return O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL, usescale=usescale)
+
+
+def load_exact_factor(p, m, usescale=False):
+    """Factor on the GPU until converged; the factor is then checked and used for apply tests."""
+    p.ilu0_factorize(90, init=capi.INIT_F_ORIGINAL, usescale=usescale, mode=capi.ASYNC)
+
+
+@pytest.mark.parametrize("case", ALL)
+@pytest.mark.parametrize("init", [capi.INIT_A_ZERO, capi.INIT_A_JACOBI])
+def test_ilu_apply_sync_sweeps_match_oracle(golden, case, init):
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    f = exact_factor(m)
+    p = make_prec(m)
+    load_exact_factor(p, m)
+    assert rel(p.get_iluvals(), f["iluvals"]) < TOL_EXACT
+    gf = p.get_iluvals()  # the oracle applies the GPU's own factor: isolates the apply kernels
+    for sweeps in (0, 1, 2, 5):
+        z = p.ilu0_apply(r, sweeps, init=init, mode=capi.JACOBI_SYNC)
+        want, wy = O.ilu0_apply(m, gf, r, sweeps, mode=O.JACOBI_SYNC, init=init, return_y=True)
+        assert rel(z, want) < TOL_SYNC
+        assert rel(p.get_ytemp(), wy) < TOL_SYNC or np.abs(wy).max() == 0
+    p.close()
+
+
+@pytest.mark.parametrize("case", ALL)
+@pytest.mark.parametrize("usescale", [False, True])
+def test_ilu_apply_async_converges_to_exact(golden, case, usescale):
+    m = matrices(golden)[case]()
+    if usescale and case.startswith("random"):
+        pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
+    n = m["nbrows"] * m["bs"]
+    f = exact_factor(m, usescale)
+    p = make_prec(m)
+    load_exact_factor(p, m, usescale)
+    for r in (np.full(n, 1.1), W.rhs_vector(n)):  # r = 1.1: async_triangular_factors_convergence.cpp:62
+        exact = O.ilu0_apply(m, f["iluvals"], r, 1, mode=O.GS_SERIAL, scale=f["scale"])
+        nsw = 60
+        for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+            z = p.ilu0_apply(r, nsw, init=init, mode=capi.ASYNC)
+            assert rel(z, exact) < TOL_EXACT
+    p.close()
+
+
+def test_ilu_apply_device_pointers_and_errors(golden):
+    import torch
+    m = matrices(golden)["poisson16_bs4"]()
+    n = m["nbrows"] * 4
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    with pytest.raises(capi.BlastedHipError) as ei:  # apply before factorize
+        p.ilu0_apply(r, 1)
+    assert ei.value.code == capi.ESTATE
+    load_exact_factor(p, m)
+    with pytest.raises(capi.BlastedHipError) as ei:  # src/solverops_ilu0.cpp:125-126
+        p.ilu0_apply(r, 1, init=capi.INIT_A_NONE)
+    assert ei.value.code == capi.EINVAL and "Invalid init type" in str(ei.value)
+    zh = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+    rd = torch.from_numpy(r).cuda()
+    zd = p.ilu0_apply(rd, 3, mode=capi.JACOBI_SYNC)
+    torch.cuda.synchronize()
+    assert np.array_equal(zd.cpu().numpy(), zh)
+    p.close()
+
+
+# ---------------------------------------------------------------------------- Jacobi / SGS / relaxation
+
+@pytest.mark.parametrize("case", ALL)
+def test_jacobi_and_sgs_match_oracle(golden, case):
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    d = O.jacobi_compute(m)
+    p = make_prec(m)
+    p.jacobi_compute()
+    assert rel(p.get_dblocks(), d) < 1e-11
+    gd = p.get_dblocks()
+    assert rel(p.jacobi_apply(r), O.jacobi_apply(m, gd, r)) < 1e-13
+    for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+        for sweeps in (0, 1, 3):
+            z = p.sgs_apply(r, sweeps, init=init, mode=capi.JACOBI_SYNC)
+            want = O.sgs_apply(m, gd, r, sweeps, mode=O.JACOBI_SYNC, init=init)
+            assert rel(z, want) < TOL_SYNC or np.abs(want).max() == 0
+    # relaxation from x = 0 and from a non-zero guess
+    for x0 in (np.zeros(n), 0.3 * np.sin(np.arange(n))):
+        for its in (1, 5):
+            x = p.sgs_relax(r, x0.copy(), its, mode=capi.JACOBI_SYNC)
+            want = O.sgs_relax(m, gd, r, x0=x0, maxits=its, mode=O.JACOBI_SYNC)
+            assert rel(x, want) < 1e-11
+    p.close()
+
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_csr", "poisson16_bs4", "poisson12_bs5", "random_bs4"])
+def test_sgs_async_converges_to_exact(golden, case):
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    exact = O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
+    nsw = 60 if case.startswith("poisson") else 80
+    z = p.sgs_apply(r, nsw, init=capi.INIT_A_ZERO, mode=capi.ASYNC)
+    assert rel(z, exact) < TOL_EXACT
+    # INIT_A_NONE: z is the initial guess of the backward sweeps
+    z2 = p.sgs_apply(r, 2, init=capi.INIT_A_NONE, mode=capi.JACOBI_SYNC, out=z.copy())
+    assert rel(z2, exact) < TOL_EXACT
+    p.close()
+
+
+def test_sgs_relax_async_reduces_residual(golden):
+    """config 3: async block-SGS relaxation, 5 sweeps; asynchronous result lies between the
+    synchronous-Jacobi and the serial Gauss-Seidel iterates in residual."""
+    m = W.poisson3d(18, 4)
+    n = m["nbrows"] * 4
+    b = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    x = p.sgs_relax(b, np.zeros(n), 5, mode=capi.ASYNC)
+    res = lambda v: np.linalg.norm(b - O.spmv(m, v)) / np.linalg.norm(b)
+    xj = O.sgs_relax(m, gd, b, maxits=5, mode=O.JACOBI_SYNC)
+    xs = O.sgs_relax(m, gd, b, maxits=5, mode=O.GS_SERIAL)
+    assert res(x) < 1.0
+    assert res(x) <= res(xj) * 1.05 and res(x) >= res(xs) * 0.5
+    p.close()
+
+
+# ---------------------------------------------------------------------------- solve-level known answers (G7)
+
+@pytest.mark.parametrize("mat,bs,rowmajor,prec", [
+    ("msc00726", 1, False, "sgs"), ("msc00726", 1, False, "ilu0"),
+    ("2dcyl1", 1, False, "ilu0"), ("2dcyl1", 4, True, "sgs"), ("2dcyl1", 4, True, "ilu0"),
+    ("2dcyl1", 4, False, "jacobi"), ("2dcyl1", 4, False, "sgs"), ("2dcyl1", 4, False, "ilu0"),
+])
+def test_solve_known_answer_on_gpu(golden, mat, bs, rowmajor, prec):
+    """tests/CMakeLists.txt:34-173 with the preconditioner and the SpMV on the GPU (ThreadedBSR4ILU0
+    style: 10 build sweeps, 15 apply sweeps, :165-173)."""
+    m = mtxio.read_mtx_bsr(G(golden, mat + ".mtx"), bs, rowmajor)
+    b = mtxio.read_mtx_dense(G(golden, mat + "_b.mtx"))
+    xk = mtxio.read_mtx_dense(G(golden, mat + "_x.mtx"))
+    p = make_prec(m)
+    if prec == "jacobi":
+        p.jacobi_compute()
+        P = lambda v: p.jacobi_apply(v)
+    elif prec == "sgs":
+        p.jacobi_compute()
+        P = lambda v: p.sgs_apply(v, 15, init=capi.INIT_A_ZERO)
+    else:
+        p.ilu0_factorize(10 if bs > 1 else 60, init=capi.INIT_F_ORIGINAL)
+        P = lambda v: p.ilu0_apply(v, 15, init=capi.INIT_A_ZERO)
+    x, its, relres = bicgstab(lambda v: p.spmv(v), P, b, 1e-10, 400)
+    assert relres < 1e-10
+    x, its, relres = bicgstab(lambda v: p.spmv(v), P, b, 1e-14, 800)
+    floor = 2e-9 if mat == "msc00726" else 0.0
+    assert np.linalg.norm(x - xk) < max(1e-8, floor)
+    p.close()
+
+
+# ---------------------------------------------------------------------------- edge cases
+
+def test_tiny_and_ragged_matrices():
+    # 1 block-row; rows with empty lower / upper parts; row count not a multiple of the rows per workgroup
+    for nb, bs in ((1, 4), (2, 5), (3, 1), (17, 4), (65, 8), (5, 3)):
+        m = W.random_bsr(nb, bs, avg_offdiag=2, seed=nb)
+        n = nb * bs
+        r = W.rhs_vector(n)
+        p = make_prec(m)
+        assert rel(p.spmv(r), O.spmv(m, r)) < 1e-13
+        p.ilu0_factorize(nb + 2, mode=capi.ASYNC)
+        f = O.ilu0_factorize(m, None, 1)["iluvals"]
+        assert rel(p.get_iluvals(), f) < TOL_EXACT
+        z = p.ilu0_apply(r, nb + 2)
+        assert rel(z, O.ilu0_apply(m, f, r, 1)) < TOL_EXACT
+        p.close()
+
+
+def test_medium_poisson_64_against_oracle():
+    """64^3 bs=4 (262144 block-rows): HIP sync sweeps == oracle sync sweeps at the bench's sweep count."""
+    m = W.poisson3d(66, 4, grid="uniform")
+    n = m["nbrows"] * 4
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)
+    want = O.ilu0_factorize(m, None, 3, mode=O.JACOBI_SYNC)["iluvals"]
+    gf = p.get_iluvals()
+    assert rel(gf, want) < TOL_SYNC
+    z = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+    assert rel(z, O.ilu0_apply(m, gf, r, 3, mode=O.JACOBI_SYNC)) < TOL_SYNC
+    # async: 3 sweeps lie between synchronous Jacobi and exact in error
+    exact = O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL)
+    za = p.ilu0_apply(r, 3, mode=capi.ASYNC)
+    assert np.abs(za - exact).max() <= np.abs(z - exact).max() * 1.0001
+    p.close()
