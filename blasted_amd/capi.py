@@ -41,6 +41,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIBPATH):
             raise ImportError("libblasted_hip.so is not built (run __graft_entry__.build()): " + LIBPATH)
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (soname
+        # libamdhip64.so.7, requested by torch as "libamdhip64.so").  If it is loaded first, our library's
+        # DT_NEEDED libamdhip64.so.7 resolves to that same copy; loaded the other way round the process
+        # ends up with two runtimes and the second one sees no GPU.  So load torch's first when present.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIBPATH)
         _lib.blasted_hip_last_error.restype = C.c_char_p
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double

@@ -106,7 +106,8 @@ def random_bsr(nbrows, bs, avg_offdiag=4, seed=12345, rowmajor=False, diag_weigh
     nedges = max(1, nbrows * avg_offdiag // 2)
     a = rng.integers(0, nbrows, nedges)
     # mostly near-diagonal neighbours plus a few far ones (bandwidth like a renumbered mesh)
-    span = np.where(rng.random(nedges) < 0.8, rng.integers(1, 12, nedges), rng.integers(1, nbrows, nedges))
+    span = np.where(rng.random(nedges) < 0.8, rng.integers(1, 12, nedges),
+                    rng.integers(1, max(nbrows, 2), nedges))
     b = (a + span) % nbrows
     keep = a != b
     a, b = a[keep], b[keep]
