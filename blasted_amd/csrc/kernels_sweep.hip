@@ -179,6 +179,8 @@ bool sweep_supported(int bs)
 
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
+	if (launch_sweep4(a, part, post, dsrc, s))
+		return;
 	switch (a.pat.bs) {
 	case 1: dispatch_layout<1>(a, part, post, dsrc, s); break;
 	case 2: dispatch_layout<2>(a, part, post, dsrc, s); break;
