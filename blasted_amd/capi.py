@@ -24,7 +24,8 @@ SYMBOLS = [
     "blasted_hip_jacobi_apply", "blasted_hip_sgs_apply", "blasted_hip_sgs_relax", "blasted_hip_spmv",
     "blasted_hip_gemv3", "blasted_hip_get_iluvals", "blasted_hip_get_dblocks", "blasted_hip_get_scale",
     "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
-    "blasted_hip_get_timing",
+    "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
+    "blasted_hip_buffer_upload", "blasted_hip_buffer_download",
 ]
 
 _lib = None

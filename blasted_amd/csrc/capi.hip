@@ -182,6 +182,39 @@ static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post,
                           double *other, const double *first_in, int nsweeps, int mode, int kind)
 {
 	Phase ph(p, kind);
+	if (nsweeps < 0) {
+		// sequential variant: in-place sweeps until one sweep changes nothing.  The stationary point of
+		// the sweep map is the result of one in-order (serial) pass, bit for bit: every row is then
+		// computed by the same expression from the final values of the rows it depends on.
+		if (first_in && first_in != x)
+			BHIP_CHECK(hipMemcpyAsync(x, first_in, sizeof(double) * (size_t)p->n(), hipMemcpyDeviceToDevice,
+			                          p->stream));
+		constexpr int BATCH = 8;
+		if (!p->flags)
+			p->flags = dev_alloc<int>(BATCH);
+		const long cap = (long)p->pat.nbrows + 2;
+		int hflags[BATCH];
+		bool stationary = false;
+		for (long done = 0; done < cap && !stationary; done += BATCH) {
+			BHIP_CHECK(hipMemsetAsync(p->flags, 0, sizeof(int) * BATCH, p->stream));
+			for (int s = 0; s < BATCH; s++) {
+				a.xin = x;
+				a.xout = x;
+				a.changed = p->flags + s;
+				launch_sweep(a, part, post, dsrc, p->stream);
+				ph.launches++;
+			}
+			BHIP_CHECK(hipMemcpyAsync(hflags, p->flags, sizeof(int) * BATCH, hipMemcpyDeviceToHost, p->stream));
+			BHIP_CHECK(hipStreamSynchronize(p->stream));
+			for (int s = 0; s < BATCH; s++)
+				if (!hflags[s])
+					stationary = true;
+		}
+		ph.done();
+		if (!stationary)
+			BHIP_FAIL(BLASTED_HIP_ERUNTIME, "sequential sweeps did not become stationary (NaN in the iterate?)");
+		return x;
+	}
 	double *cur = x;
 	for (int s = 0; s < nsweeps; s++) {
 		const double *in = (s == 0 && first_in) ? first_in : cur;
@@ -274,6 +307,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 			dev_free(p->stage[i]);
 		}
 		dev_free(p->red);
+		dev_free(p->flags);
 		if (p->own_stream)
 			(void)hipStreamDestroy(p->stream);
 		delete p;
@@ -417,8 +451,6 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
-		if (nbuildsweeps < 0)
-			BHIP_FAIL(BLASTED_HIP_EINVAL, "negative sweep count");
 		if (fact_init < BLASTED_HIP_INIT_F_ZERO || fact_init > BLASTED_HIP_INIT_F_NONE)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "Factor initialization not recongnized!");
 		const Pattern &pat = p->pat;
@@ -457,6 +489,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.posptr = p->posptr;
 		fa.lowerp = p->lowerp;
 		fa.upperp = p->upperp;
+		fa.changed = nullptr;
 
 		const long ngroups = (long)pat.nbrows + 8;
 		if (precinfo) {
@@ -470,7 +503,35 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 
 		// async_bilu0_sweeps, src/async_blockilu_factor.cpp:186-204
 		double *cur = p->iluvals;
-		{
+		if (nbuildsweeps < 0) {
+			// sequential factorisation (seqilu0 / sfilu0): sweep in place until stationary, see run_sweeps
+			Phase ph(p, 0);
+			constexpr int BATCH = 8;
+			if (!p->flags)
+				p->flags = dev_alloc<int>(BATCH);
+			const long cap = (long)pat.nnzb + 2;
+			int hflags[BATCH];
+			bool stationary = false;
+			fa.in = p->iluvals;
+			fa.out = p->iluvals;
+			for (long done = 0; done < cap && !stationary; done += BATCH) {
+				BHIP_CHECK(hipMemsetAsync(p->flags, 0, sizeof(int) * BATCH, p->stream));
+				for (int s = 0; s < BATCH; s++) {
+					fa.changed = p->flags + s;
+					launch_factor_sweep(fa, p->stream);
+					ph.launches++;
+				}
+				BHIP_CHECK(hipMemcpyAsync(hflags, p->flags, sizeof(int) * BATCH, hipMemcpyDeviceToHost, p->stream));
+				BHIP_CHECK(hipStreamSynchronize(p->stream));
+				for (int s = 0; s < BATCH; s++)
+					if (!hflags[s])
+						stationary = true;
+			}
+			ph.done();
+			fa.changed = nullptr;
+			if (!stationary)
+				BHIP_FAIL(BLASTED_HIP_ERUNTIME, "sequential factorisation did not become stationary");
+		} else {
 			Phase ph(p, 0);
 			for (int s = 0; s < nbuildsweeps; s++) {
 				double *out = cur;
@@ -526,8 +587,10 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_apply before ilu0_factorize");
 		if (apply_init != BLASTED_HIP_INIT_A_ZERO && apply_init != BLASTED_HIP_INIT_A_JACOBI)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, " scalar_ilu0_apply: Invalid init type!");
-		if (!r || !z || napplysweeps < 0)
-			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_apply: null vector or negative sweep count");
+		if (!r || !z)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_apply: null vector");
+		if (napplysweeps < 0)
+			mode = BLASTED_HIP_ASYNC;  // sequential variant: always in place
 		const long n = p->n();
 		const size_t nbytes = sizeof(double) * (size_t)n;
 		const double *dr = in_vec(p, r, loc, 0);
@@ -660,8 +723,10 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		check_loc(loc);
 		check_mode(mode);
 		need_jacobi(p);
-		if (!r || !z || napplysweeps < 0)
-			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_apply: null vector or negative sweep count");
+		if (!r || !z)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_apply: null vector");
+		if (napplysweeps < 0)
+			mode = BLASTED_HIP_ASYNC;
 		if (apply_init < BLASTED_HIP_INIT_A_ZERO || apply_init > BLASTED_HIP_INIT_A_NONE)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "Apply initialization not recongnized!");
 		const long n = p->n();
@@ -846,6 +911,45 @@ int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr)
 		if (!p->iluvals || !dev_ptr)
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "iluvals is not available");
 		*dev_ptr = p->iluvals;
+	});
+}
+
+/* ---- raw buffers --------------------------------------------------------------------------- */
+
+int blasted_hip_buffer_alloc(void **dev_ptr, unsigned long nbytes, int device)
+{
+	return guarded([&] {
+		if (!dev_ptr)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "null output pointer");
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+			BHIP_FAIL(BLASTED_HIP_ENODEV, "no HIP device available: the MI355X backend has no CPU fallback");
+		BHIP_CHECK(hipSetDevice(device));
+		BHIP_CHECK(hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+	});
+}
+
+int blasted_hip_buffer_free(void *dev_ptr)
+{
+	return guarded([&] {
+		if (dev_ptr)
+			BHIP_CHECK(hipFree(dev_ptr));
+	});
+}
+
+int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long nbytes)
+{
+	return guarded([&] {
+		if (nbytes)
+			BHIP_CHECK(hipMemcpy(dev_ptr, host_ptr, nbytes, hipMemcpyHostToDevice));
+	});
+}
+
+int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes)
+{
+	return guarded([&] {
+		if (nbytes)
+			BHIP_CHECK(hipMemcpy(host_ptr, dev_ptr, nbytes, hipMemcpyDeviceToHost));
 	});
 }
 

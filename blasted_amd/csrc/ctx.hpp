@@ -66,6 +66,7 @@ struct SweepArgs {
 	double *xout;           // written iterate (== xin for in-place async sweeps)
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
+	int *changed;           // optional flag: set to 1 if any stored value differs from the old one
 };
 
 struct FactorArgs {
@@ -75,6 +76,7 @@ struct FactorArgs {
 	const int *posptr, *lowerp, *upperp;
 	const double *in;       // factor values read
 	double *out;            // factor values written (== in for async)
+	int *changed;           // optional flag, as in SweepArgs
 };
 
 // kernels_sweep.hip
@@ -137,6 +139,7 @@ struct blasted_hip_prec_s {
 	double *tmp[3] = {nullptr, nullptr, nullptr};    // n-vectors: Jacobi-sync ping-pong
 	double *stage[3] = {nullptr, nullptr, nullptr};  // n-vectors: device copies of host vectors
 	double *red = nullptr;                           // small reduction scratch
+	int *flags = nullptr;                            // per-sweep 'changed' flags (sequential variants)
 
 	bhip::Timing timing;
 

@@ -183,10 +183,16 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 				const double inv = group_inverse<BS, BSP>(dv, gbase, r, c);
 				res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
 			}
-			if (active)
+			if (active) {
+				if (a.changed && !(a.out[(long)jpos * BS2 + e] == res))
+					*a.changed = 1;
 				a.out[(long)jpos * BS2 + e] = res;
-		} else if (active)
+			}
+		} else if (active) {
+			if (a.changed && !(a.out[(long)jpos * BS2 + e] == s))
+				*a.changed = 1;
 			a.out[(long)jpos * BS2 + e] = s;
+		}
 	}
 
 	if (RESID) {

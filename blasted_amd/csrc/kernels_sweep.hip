@@ -136,8 +136,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 			out += a.b * rv;
 	}
 
-	if (rowok && sub == 0 && c == 0 && r < BS)
+	if (rowok && sub == 0 && c == 0 && r < BS) {
+		if (a.changed && !(a.xout[(long)i * BS + r] == out))
+			*a.changed = 1;
 		a.xout[(long)i * BS + r] = out;
+	}
 }
 
 template <int BS, bool RM>

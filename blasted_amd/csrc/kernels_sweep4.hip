@@ -265,7 +265,13 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 				double2_t o2;
 				o2.x = o0;
 				o2.y = o1;
-				*reinterpret_cast<double2_t *>(a.xout + (long)irow[u] * 4 + 2 * q) = o2;
+				double2_t *const dst = reinterpret_cast<double2_t *>(a.xout + (long)irow[u] * 4 + 2 * q);
+				if (a.changed) {
+					const double2_t old = *dst;
+					if (!(old.x == o0) || !(old.y == o1))
+						*a.changed = 1;
+				}
+				*dst = o2;
 			}
 		}
 	}

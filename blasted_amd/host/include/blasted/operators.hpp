@@ -1,0 +1,286 @@
+// operators.hpp -- the operator classes of the BLASTed API on the MI355X backend.
+//
+// Same class names, constructor argument lists, virtual interface and error behaviour as the reference:
+//   AbstractLinearOperator, MatrixView          include/linearoperator.hpp:17-131
+//   Preconditioner, SRPreconditioner, NoPreconditioner   include/solverops_base.hpp:31-106
+//   JacobiSRPreconditioner, BJacobiSRPreconditioner      include/solverops_jacobi.hpp
+//   AsyncSGS_SRPreconditioner, AsyncBlockSGS_SRPreconditioner   include/solverops_sgs.hpp:23-121
+//   AsyncILU0_SRPreconditioner, AsyncBlockILU0_SRPreconditioner include/solverops_ilu0.hpp:23-169
+//   SRMatrixView, BSRMatrixView, CSRMatrixView (apply / gemv3 only)  include/blockmatrices.hpp:27-160
+// What is different is where the work happens: every compute()/apply()/apply_relax()/gemv3() forwards to
+// the C ABI of include/blasted_hip.h; there is no host arithmetic in these classes.  Vectors passed to
+// the reference signatures are host pointers (as PETSc's VecGetArray gives them); the *_device variants
+// take HBM pointers and never cross PCIe.
+//
+// Knobs without a GPU meaning keep their place in the signatures: thread_chunk_size is accepted and
+// ignored; threadedfactor / threadedapply = false (the seq* / sf* / sap* factory types) select the exact
+// sequential result, obtained on the device by sweeping until the iterate is bitwise stationary.
+#pragma once
+
+#include <memory>
+#include <string>
+
+#include "storage.hpp"
+#include "types.hpp"
+
+struct blasted_hip_prec_s;
+
+namespace blasted {
+
+namespace detail {
+
+/// RAII owner of one blasted_hip_prec; translates C-ABI error codes into the reference's exceptions
+class HipOperator {
+public:
+	HipOperator();
+	~HipOperator();
+	HipOperator(const HipOperator &) = delete;
+	HipOperator &operator=(const HipOperator &) = delete;
+
+	/// Uploads the pattern on first use, (re-)sets the values every time
+	void bind(const CRawBSRMatrix<double, int> &mat, int bs, StorageOptions stor);
+	blasted_hip_prec_s *get() const { return h; }
+	static void check(int rc);
+	/// BLASTED_HIP_ASYNC unless the environment asks for deterministic synchronous sweeps
+	static int sweep_mode();
+	static int default_device();
+
+private:
+	blasted_hip_prec_s *h;
+	bool pattern_set;
+};
+
+}  // namespace detail
+
+template <typename scalar, typename index>
+class AbstractLinearOperator {
+public:
+	explicit AbstractLinearOperator(const StorageType storagetype) : _type{storagetype} {}
+	virtual ~AbstractLinearOperator() {}
+	StorageType type() { return _type; }
+	virtual index dim() const = 0;
+	virtual void apply(const scalar *const x, scalar *const __restrict y) const = 0;
+
+protected:
+	StorageType _type;
+};
+
+template <typename scalar, typename index>
+class MatrixView : public AbstractLinearOperator<scalar, index> {
+public:
+	explicit MatrixView(const StorageType storagetype) : AbstractLinearOperator<scalar, index>(storagetype) {}
+	virtual ~MatrixView() {}
+	virtual void apply(const scalar *const x, scalar *const __restrict y) const = 0;
+	/// z := a A x + b y
+	virtual void gemv3(const scalar a, const scalar *const __restrict x, const scalar b,
+	                   const scalar *const y, scalar *const z) const = 0;
+};
+
+/// View of a sparse-row matrix (not owning unless the storage does)
+template <typename scalar, typename index>
+class SRMatrixView : public MatrixView<scalar, index> {
+public:
+	SRMatrixView(SRMatrixStorage<const scalar, const index> &&matrix, const StorageType storagetype,
+	             const int block_size, const StorageOptions layout);
+	virtual ~SRMatrixView();
+	const SRMatrixStorage<const scalar, const index> &getSRStorage() const { return mat; }
+	index dim() const { return mat.nbrows * bs_; }
+	void apply(const scalar *const x, scalar *const __restrict y) const;
+	void gemv3(const scalar a, const scalar *const __restrict x, const scalar b, const scalar *const y,
+	           scalar *const z) const;
+	/// HBM-resident vectors
+	void apply_device(const scalar *const dx, scalar *const dy) const;
+
+protected:
+	SRMatrixStorage<const scalar, const index> mat;
+	int bs_;
+	std::unique_ptr<detail::HipOperator> op;
+};
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class BSRMatrixView : public SRMatrixView<scalar, index> {
+	static_assert(bs > 0, "Block size must be positive!");
+
+public:
+	explicit BSRMatrixView(SRMatrixStorage<const scalar, const index> &&matrix)
+	    : SRMatrixView<scalar, index>(std::move(matrix), VIEWBSR, bs, stor)
+	{
+	}
+};
+
+template <typename scalar, typename index>
+class CSRMatrixView : public SRMatrixView<scalar, index> {
+public:
+	explicit CSRMatrixView(SRMatrixStorage<const scalar, const index> &&matrix)
+	    : SRMatrixView<scalar, index>(std::move(matrix), VIEWCSR, 1, ColMajor)
+	{
+	}
+};
+
+template <typename scalar, typename index>
+class Preconditioner : public AbstractLinearOperator<scalar, index> {
+public:
+	explicit Preconditioner(const StorageType storagetype) : AbstractLinearOperator<scalar, index>(storagetype) {}
+	virtual ~Preconditioner() {}
+	virtual index dim() const = 0;
+	virtual PrecInfo compute() = 0;
+	virtual void apply(const scalar *const x, scalar *const __restrict y) const = 0;
+	virtual void apply_relax(const scalar *const x, scalar *const __restrict y) const = 0;
+	virtual bool relaxationAvailable() const = 0;
+	void setApplyParams(const SolveParams<scalar> sparams) { solveparams = sparams; }
+
+protected:
+	SolveParams<scalar> solveparams{};
+};
+
+/// Preconditioner built from a sparse-row matrix; holds the storage (pmat) and its raw view (mat)
+template <typename scalar, typename index>
+class SRPreconditioner : public Preconditioner<scalar, index> {
+public:
+	explicit SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix);
+	virtual ~SRPreconditioner();
+	/// apply / apply_relax on HBM-resident vectors (stream ordered; no host copy)
+	virtual void apply_device(const scalar *const dx, scalar *const dy) const;
+	virtual void apply_relax_device(const scalar *const db, scalar *const dx) const;
+
+protected:
+	SRMatrixStorage<const scalar, const index> pmat;
+	CRawBSRMatrix<scalar, index> mat;
+	std::unique_ptr<detail::HipOperator> op;
+};
+
+template <typename scalar, typename index>
+class NoPreconditioner : public SRPreconditioner<scalar, index> {
+public:
+	NoPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix, const index bs);
+	index dim() const { return ndim; }
+	bool relaxationAvailable() const { return false; }
+	PrecInfo compute() { return PrecInfo(); }
+	void apply(const scalar *const x, scalar *const __restrict y) const;
+	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
+
+protected:
+	index ndim;
+};
+
+/// Block-Jacobi: dblocks_i = A_ii^-1 (in HBM)
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class BJacobiSRPreconditioner : public SRPreconditioner<scalar, index> {
+	static_assert(bs > 0, "Block size must be positive!");
+
+public:
+	explicit BJacobiSRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix);
+	virtual ~BJacobiSRPreconditioner();
+	index dim() const { return mat.nbrows * bs; }
+	bool relaxationAvailable() const { return false; }
+	PrecInfo compute();
+	void apply(const scalar *const r, scalar *const __restrict z) const;
+	/// the reference's Jacobi relaxation (src/solverops_jacobi.cpp:66-130) is not on the GPU path
+	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
+	void apply_device(const scalar *const dx, scalar *const dy) const;
+
+protected:
+	using SRPreconditioner<scalar, index>::mat;
+	using SRPreconditioner<scalar, index>::op;
+	using SRPreconditioner<scalar, index>::solveparams;
+	void bind_and_invert();
+};
+
+template <typename scalar, typename index>
+class JacobiSRPreconditioner : public BJacobiSRPreconditioner<scalar, index, 1, ColMajor> {
+public:
+	explicit JacobiSRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix)
+	    : BJacobiSRPreconditioner<scalar, index, 1, ColMajor>(std::move(matrix))
+	{
+	}
+};
+
+/// Asynchronous block symmetric Gauss-Seidel
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class AsyncBlockSGS_SRPreconditioner : public BJacobiSRPreconditioner<scalar, index, bs, stor> {
+public:
+	AsyncBlockSGS_SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix,
+	                               const int napplysweeps, const ApplyInit apply_inittype,
+	                               const int threadchunksize);
+	~AsyncBlockSGS_SRPreconditioner();
+	bool relaxationAvailable() const { return true; }
+	PrecInfo compute();
+	void apply(const scalar *const r, scalar *const __restrict z) const;
+	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
+	void apply_device(const scalar *const dr, scalar *const dz) const;
+	void apply_relax_device(const scalar *const db, scalar *const dx) const;
+
+protected:
+	using SRPreconditioner<scalar, index>::mat;
+	using SRPreconditioner<scalar, index>::op;
+	using SRPreconditioner<scalar, index>::solveparams;
+	const int napplysweeps;
+	const ApplyInit ainit;
+	const int thread_chunk_size;
+};
+
+template <typename scalar, typename index>
+class AsyncSGS_SRPreconditioner : public AsyncBlockSGS_SRPreconditioner<scalar, index, 1, ColMajor> {
+public:
+	AsyncSGS_SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix, const int napplysweeps,
+	                          const ApplyInit apply_inittype, const int threadchunksize)
+	    : AsyncBlockSGS_SRPreconditioner<scalar, index, 1, ColMajor>(std::move(matrix), napplysweeps,
+	                                                                   apply_inittype, threadchunksize)
+	{
+	}
+};
+
+/// Asynchronous block ILU(0): async fixed-point factorisation + async triangular sweeps
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class AsyncBlockILU0_SRPreconditioner : public SRPreconditioner<scalar, index> {
+	static_assert(bs > 0, "Block size must be positive!");
+	static_assert(stor == RowMajor || stor == ColMajor, "Invalid storage option!");
+
+public:
+	AsyncBlockILU0_SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix,
+	                                const int nbuildsweeps, const int napplysweeps, const bool use_scaling,
+	                                const int thread_chunk_size, const FactInit fact_inittype,
+	                                const ApplyInit apply_inittype, const bool threadedfactor = true,
+	                                const bool threadedapply = true, const bool compute_remainder = false);
+	~AsyncBlockILU0_SRPreconditioner();
+	index dim() const { return mat.nbrows * bs; }
+	bool relaxationAvailable() const { return false; }
+	/// successive calls must keep the sparsity pattern (values may change)
+	PrecInfo compute();
+	void apply(const scalar *const x, scalar *const __restrict y) const;
+	/// throws std::runtime_error, as the reference does
+	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
+	void apply_device(const scalar *const dr, scalar *const dz) const;
+
+protected:
+	using SRPreconditioner<scalar, index>::mat;
+	using SRPreconditioner<scalar, index>::op;
+	const bool usescaling;
+	const bool threadedfactor;
+	const bool threadedapply;
+	const int nbuildsweeps;
+	const int napplysweeps;
+	const int thread_chunk_size;
+	const FactInit factinittype;
+	const ApplyInit applyinittype;
+	const bool compute_remainder;
+};
+
+/// Scalar ILU(0).  Note the reference's argument order: compute_preconditioner_info comes BEFORE the
+/// threaded flags here (include/solverops_ilu0.hpp:113-118).
+template <typename scalar, typename index>
+class AsyncILU0_SRPreconditioner : public AsyncBlockILU0_SRPreconditioner<scalar, index, 1, ColMajor> {
+public:
+	AsyncILU0_SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix, const int nbuildsweeps,
+	                           const int napplysweeps, const bool use_scaling, const int thread_chunk_size,
+	                           const FactInit fact_inittype, const ApplyInit apply_inittype,
+	                           const bool compute_preconditioner_info, const bool threadedfactor = true,
+	                           const bool threadedapply = true)
+	    : AsyncBlockILU0_SRPreconditioner<scalar, index, 1, ColMajor>(
+	          std::move(matrix), nbuildsweeps, napplysweeps, use_scaling, thread_chunk_size, fact_inittype,
+	          apply_inittype, threadedfactor, threadedapply, compute_preconditioner_info)
+	{
+	}
+};
+
+}  // namespace blasted

@@ -1,0 +1,3 @@
+// device_container.hpp -- reference header name kept for drop-in source compatibility
+#pragma once
+#include "blasted/storage.hpp"

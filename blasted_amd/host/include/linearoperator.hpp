@@ -1,0 +1,3 @@
+// linearoperator.hpp -- reference header name kept for drop-in source compatibility
+#pragma once
+#include "blasted/operators.hpp"

@@ -1,0 +1,3 @@
+// preconditioner_diagnostics.hpp -- reference header name kept for drop-in source compatibility
+#pragma once
+#include "blasted/types.hpp"

@@ -1,0 +1,3 @@
+// solverfactory.hpp -- reference header name kept for drop-in source compatibility
+#pragma once
+#include "blasted/factory.hpp"

@@ -1,0 +1,3 @@
+// solverops_ilu0.hpp -- reference header name kept for drop-in source compatibility
+#pragma once
+#include "blasted/operators.hpp"

@@ -1,0 +1,534 @@
+// blasted_petsc.cpp -- PCSHELL glue between PETSc and the MI355X operators.
+//
+// Behaviour follows the reference's src/blasted_petsc.cpp (options :136-213, object creation :216-311,
+// callbacks :403-575, tree walk :578-661, installation :663-721, timers :723-735), with two deliberate
+// differences:
+//  * the rank-local matrix is reached through PETSc's PUBLIC interface (MatGetRowIJ,
+//    MatSeqAIJGetArrayRead, MatSeqBAIJGetArray) instead of the private Mat_SeqAIJ / Mat_SeqBAIJ structs
+//    (src/blasted_petsc.cpp:14-15,285-297); the diagonal positions are found by one scan of the rows;
+//  * bctx->prectype is set before it is consulted when the Richardson callback is installed (the
+//    reference reads it uninitialised).
+// Built only when PETSc is available (make petsc PETSC_DIR=... PETSC_ARCH=...).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "blasted_petsc_ext.hpp"
+
+using namespace blasted;
+
+typedef SRPreconditioner<PetscReal, PetscInt> BlastedPreconditioner;
+typedef FactoryBase<PetscReal, PetscInt> BlastedFactory;
+
+namespace {
+
+/// borrowed PETSc arrays + the diagonal positions this glue owns, kept next to the operator
+struct LocalMatrix {
+	std::vector<PetscInt> diag;
+};
+
+// side table: operator -> arrays this glue allocated for it (they must outlive the operator)
+std::map<void *, LocalMatrix *> g_local_matrices;
+void register_local_matrix(void *op, LocalMatrix *lm)
+{
+	g_local_matrices[op] = lm;
+}
+void release_local_matrix(void *op)
+{
+	auto it = g_local_matrices.find(op);
+	if (it != g_local_matrices.end()) {
+		delete it->second;
+		g_local_matrices.erase(it);
+	}
+}
+
+struct StopWatch {
+	std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
+	std::clock_t c0 = std::clock();
+	void add_to(double &wall, double &cpu) const
+	{
+		wall += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+		cpu += (double)(std::clock() - c0) / CLOCKS_PER_SEC;
+	}
+};
+
+void require(const PetscBool found, const char *const tag)
+{
+	if (!found) {  // missing mandatory option: the reference aborts (src/blasted_petsc.cpp:36-39,81-84)
+		std::printf("BLASTed: %s not set!\n", tag);
+		std::fflush(stdout);
+		std::abort();
+	}
+}
+
+int mandatory_int(const char *const tag)
+{
+	PetscBool set = PETSC_FALSE;
+	PetscInt val = 0;
+	PetscOptionsGetInt(NULL, NULL, tag, &val, &set);
+	require(set, tag);
+	return (int)val;
+}
+
+bool mandatory_bool(const char *const tag)
+{
+	PetscBool set = PETSC_FALSE, val = PETSC_FALSE;
+	if (PetscOptionsGetBool(NULL, NULL, tag, &val, &set))
+		throw std::runtime_error("Petsc could not get optional bool option!");
+	if (!set)
+		throw std::runtime_error("Bool option " + std::string(tag) + " not set!");
+	return val == PETSC_TRUE;
+}
+
+bool optional_bool(const char *const tag, const bool dflt)
+{
+	PetscBool set = PETSC_FALSE, val = dflt ? PETSC_TRUE : PETSC_FALSE;
+	if (PetscOptionsGetBool(NULL, NULL, tag, &val, &set))
+		throw std::runtime_error("Petsc could not get optional bool option!");
+	if (!set)
+		std::printf(" BLASTed: %s not set; using default value of %d\n", tag, (int)dflt);
+	return val == PETSC_TRUE;
+}
+
+void mandatory_string(const char *const tag, char out[BLASTED_OPT_STRLEN])
+{
+	PetscBool set = PETSC_FALSE;
+	PetscOptionsGetString(NULL, NULL, tag, out, BLASTED_OPT_STRLEN, &set);
+	require(set, tag);
+}
+
+bool needs_async_params(const BlastedSolverType t)
+{
+	return t != BLASTED_JACOBI && t != BLASTED_LEVEL_SGS && t != BLASTED_NO_PREC;
+}
+
+bool has_factorisation(const BlastedSolverType t)
+{
+	return t == BLASTED_ILU0 || t == BLASTED_SAPILU0 || t == BLASTED_ASYNC_LEVEL_ILU0;
+}
+
+/// sweep count -1 selects the sequential variants (src/blasted_petsc.cpp:88-133)
+void resolve_sequential(const Blasted_data *const ctx, AsyncSolverSettings &s)
+{
+	static_assert(BLASTED_SEQUENTIAL_SYMBOL < 0, "Symbol of sequential build/apply must be -ve!");
+	s.nbuildsweeps = ctx->nbuildsweeps;
+	s.napplysweeps = ctx->napplysweeps;
+	if (s.prectype == BLASTED_SEQILU0)
+		return;
+	const bool seqa = ctx->napplysweeps == BLASTED_SEQUENTIAL_SYMBOL;
+	const bool seqb = ctx->nbuildsweeps == BLASTED_SEQUENTIAL_SYMBOL;
+	if ((seqa && seqb) || (seqa && s.prectype == BLASTED_SFILU0) || (seqb && s.prectype == BLASTED_SAPILU0)) {
+		s.prectype = BLASTED_SEQILU0;
+		s.nbuildsweeps = s.napplysweeps = 1;
+		return;
+	}
+	if (seqa) {
+		if (s.prectype != BLASTED_ILU0 && s.prectype != BLASTED_SAPILU0)
+			throw std::runtime_error(" Seq. appl. only supported with async ILU factorization!");
+		s.napplysweeps = 1;
+		s.prectype = BLASTED_SAPILU0;
+		std::printf("  Sequential application requested.\n");
+	}
+	if (seqb) {
+		if (s.prectype != BLASTED_ILU0 && s.prectype != BLASTED_SFILU0)
+			throw std::runtime_error(" Seq. fact. only supported with async triangular application!");
+		s.nbuildsweeps = 1;
+		s.prectype = BLASTED_SFILU0;
+		std::printf("  Sequential factorization requested.\n");
+	}
+}
+
+PetscErrorCode read_options(PC pc)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	const BlastedFactory *const factory = (const BlastedFactory *)ctx->bfactory;
+
+	mandatory_string("-blasted_pc_type", ctx->prectypestr);
+	const BlastedSolverType ptype = factory->solverTypeFromString(ctx->prectypestr);
+
+	PetscInt sweeps[2] = {1, 1};
+	if (needs_async_params(ptype)) {
+		PetscBool set = PETSC_FALSE;
+		PetscInt nmax = 2;
+		PetscOptionsGetIntArray(NULL, NULL, "-blasted_async_sweeps", sweeps, &nmax, &set);
+		if (!set || nmax < 2) {
+			std::printf("BLASTed: Number of async sweeps not set properly!\n");
+			std::fflush(stdout);
+			std::abort();
+		}
+		if (has_factorisation(ptype)) {
+			ctx->scale = mandatory_bool("-blasted_use_symmetric_scaling");
+			mandatory_string("-blasted_async_fact_init_type", ctx->factinittype);
+		} else {
+			ctx->scale = false;
+			std::strcpy(ctx->factinittype, "NA");
+		}
+		mandatory_string("-blasted_async_apply_init_type", ctx->applyinittype);
+		ctx->threadchunksize = mandatory_int("-blasted_thread_chunk_size");
+	}
+	ctx->compute_precinfo = optional_bool("-blasted_compute_preconditioner_info", false);
+
+	ctx->bprec = nullptr;
+	ctx->prectype = ptype;
+	ctx->nbuildsweeps = (int)sweeps[0];
+	ctx->napplysweeps = (int)sweeps[1];
+	ctx->first_setup_done = true;
+	ctx->cputime = ctx->walltime = ctx->factorcputime = ctx->factorwalltime = ctx->applycputime =
+	    ctx->applywalltime = 0;
+
+	const std::string pcname = std::string("Blasted-") + ctx->prectypestr;
+	ierr = PCShellSetName(pc, pcname.c_str()); CHKERRQ(ierr);
+	return ierr;
+}
+
+/// Wraps the rank-local (block-)row arrays of the PC's matrix, zero copy, and creates the operator
+PetscErrorCode create_operator(PC pc)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	delete reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+	ctx->bprec = nullptr;
+
+	Mat A;
+	ierr = PCGetOperators(pc, NULL, &A); CHKERRQ(ierr);
+	PetscInt localrows, localcols;
+	ierr = MatGetLocalSize(A, &localrows, &localcols); CHKERRQ(ierr);
+	if (localrows != localcols)
+		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_SIZ, "BLASTed: the local matrix must be square");
+
+	PetscBool diagmissing = PETSC_FALSE;
+	PetscInt badrow = -1;
+	ierr = MatMissingDiagonal(A, &diagmissing, &badrow); CHKERRQ(ierr);
+	if (diagmissing)
+		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "! Zero diagonal in a (block-)row!");
+
+	const BlastedFactory *const factory = (const BlastedFactory *)ctx->bfactory;
+	AsyncSolverSettings settings;
+	settings.prectype = factory->solverTypeFromString(ctx->prectypestr);
+	settings.bs = ctx->bs;
+	settings.blockstorage = ColMajor;  // PETSc BAIJ blocks are column-major
+	settings.scale = ctx->scale;
+	resolve_sequential(ctx, settings);
+	settings.thread_chunk_size = ctx->threadchunksize;
+	settings.compute_precinfo = ctx->compute_precinfo;
+	settings.fact_inittype = INIT_F_NONE;
+	settings.apply_inittype = INIT_A_NONE;
+	if (needs_async_params(settings.prectype)) {
+		if (has_factorisation(settings.prectype))
+			settings.fact_inittype = getFactInitFromString(ctx->factinittype);
+		settings.apply_inittype = getApplyInitFromString(ctx->applyinittype);
+	}
+	settings.relax = false;
+
+	if (ctx->bs <= 0 || ctx->bs == 6 || ctx->bs > 8)
+		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "BLASTed: this block size is not supported!");
+
+	// block-row structure and values through the public interface
+	PetscInt nbr = 0;
+	const PetscInt *ia = NULL, *ja = NULL;
+	PetscBool done = PETSC_FALSE;
+	ierr = MatGetRowIJ(A, 0, PETSC_FALSE, ctx->bs > 1 ? PETSC_TRUE : PETSC_FALSE, &nbr, &ia, &ja, &done);
+	CHKERRQ(ierr);
+	if (!done || nbr != localrows / ctx->bs)
+		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "BLASTed: could not access the (block-)row structure");
+	const PetscScalar *vals = NULL;
+	if (ctx->bs == 1) {
+		ierr = MatSeqAIJGetArrayRead(A, &vals); CHKERRQ(ierr);
+	} else {
+		PetscScalar *v = NULL;
+		ierr = MatSeqBAIJGetArray(A, &v); CHKERRQ(ierr);
+		vals = v;
+	}
+
+	// diagonal positions (integer scan, once per pattern); the vector lives as long as the operator
+	LocalMatrix *lm = new LocalMatrix;
+	lm->diag.resize(nbr);
+	for (PetscInt i = 0; i < nbr; i++) {
+		PetscInt d = -1;
+		for (PetscInt j = ia[i]; j < ia[i + 1]; j++)
+			if (ja[j] == i) {
+				d = j;
+				break;
+			}
+		if (d < 0) {
+			delete lm;
+			SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "! Missing diagonal block!");
+		}
+		lm->diag[i] = d;
+	}
+
+	BlastedPreconditioner *precop = factory->create_preconditioner(
+	    SRMatrixStorage<const PetscReal, const PetscInt>(ia, ja, vals, lm->diag.data(), ia + 1, nbr, ia[nbr],
+	                                                     ia[nbr], ctx->bs),
+	    settings);
+	ctx->bprec = reinterpret_cast<void *>(precop);
+	register_local_matrix(ctx->bprec, lm);  // released in cleanup_blasted together with the operator
+
+	ctx->infolist = NULL;
+	if (ctx->compute_precinfo) {
+		PrecInfoList *bpinfo = new PrecInfoList;
+		bpinfo->infolist.reserve(250);
+		ctx->infolist = static_cast<void *>(bpinfo);
+	}
+	return ierr;
+}
+
+}  // namespace
+
+extern "C" {
+
+Blasted_data_list newBlastedDataList()
+{
+	Blasted_data_list b;
+	b.ctxlist = NULL;
+	b.size = 0;
+	b.bfactory = NULL;
+	b._defaultfactory = 0;
+	b.factorcputime = b.factorwalltime = b.applycputime = b.applywalltime = 0.0;
+	return b;
+}
+
+void destroyBlastedDataList(Blasted_data_list *const b)
+{
+	if (b->_defaultfactory == 1) {
+		delete (BlastedFactory *)b->bfactory;
+		b->_defaultfactory = 0;
+	}
+	while (b->ctxlist != NULL) {
+		Blasted_data *node = b->ctxlist;
+		b->ctxlist = node->next;
+		delete static_cast<PrecInfoList *>(node->infolist);
+		delete node;
+		b->size--;
+	}
+	if (b->size != 0)
+		throw std::logic_error("Could not delete Blasted_data_list properly!");
+}
+
+Blasted_data newBlastedDataContext()
+{
+	Blasted_data ctx;
+	std::memset(&ctx, 0, sizeof(ctx));
+	ctx.bprec = NULL;
+	ctx.infolist = NULL;
+	ctx.first_setup_done = false;
+	ctx.next = NULL;
+	return ctx;
+}
+
+void appendBlastedDataContext(Blasted_data_list *const bdl, const Blasted_data bd)
+{
+	Blasted_data *node = new Blasted_data;
+	*node = bd;
+	node->next = bdl->ctxlist;
+	bdl->ctxlist = node;
+	bdl->size++;
+}
+
+PetscErrorCode cleanup_blasted(PC pc)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	release_local_matrix(ctx->bprec);
+	delete reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+	ctx->bprec = NULL;
+	return ierr;
+}
+
+PetscErrorCode compute_preconditioner_blasted(PC pc)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	if (!ctx->first_setup_done) {
+		ierr = read_options(pc); CHKERRQ(ierr);
+		ierr = create_operator(pc); CHKERRQ(ierr);
+	}
+	const StopWatch sw;
+	BlastedPreconditioner *const precop = reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+	const PrecInfo pinfo = precop->compute();  // values H2D + factorisation on the GPU
+	if (ctx->compute_precinfo)
+		static_cast<PrecInfoList *>(ctx->infolist)->infolist.push_back(pinfo);
+	sw.add_to(ctx->factorwalltime, ctx->factorcputime);
+	return ierr;
+}
+
+PetscErrorCode apply_local_blasted(PC pc, Vec r, Vec z)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	const BlastedPreconditioner *const prec = reinterpret_cast<const BlastedPreconditioner *>(ctx->bprec);
+	const PetscReal *ra;
+	PetscReal *za;
+	ierr = VecGetArray(z, &za); CHKERRQ(ierr);
+	ierr = VecGetArrayRead(r, &ra); CHKERRQ(ierr);
+	{
+		const StopWatch sw;
+		prec->apply(ra, za);  // host vectors: r H2D, sweeps, z D2H
+		sw.add_to(ctx->applywalltime, ctx->applycputime);
+	}
+	ierr = VecRestoreArrayRead(r, &ra); CHKERRQ(ierr);
+	ierr = VecRestoreArray(z, &za); CHKERRQ(ierr);
+	return ierr;
+}
+
+PetscErrorCode relax_local_blasted(PC pc, Vec rhs, Vec x, Vec w, const PetscReal rtol, const PetscReal abstol,
+                                   const PetscReal dtol, const PetscInt it, const PetscBool guesszero,
+                                   PetscInt *const outits, PCRichardsonConvergedReason *const reason)
+{
+	Blasted_data *ctx;
+	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	BlastedPreconditioner *const relaxation = reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+	// only the iteration count is used; SGS never checks tolerances (src/solverops_sgs.cpp:96-115)
+	relaxation->setApplyParams({rtol, abstol, dtol, false, (int)it});
+	if (guesszero) {
+		ierr = VecSet(x, 0.0); CHKERRQ(ierr);
+	}
+	const PetscReal *ba;
+	PetscReal *xa;
+	ierr = VecGetArray(x, &xa); CHKERRQ(ierr);
+	ierr = VecGetArrayRead(rhs, &ba); CHKERRQ(ierr);
+	{
+		const StopWatch sw;
+		relaxation->apply_relax(ba, xa);
+		sw.add_to(ctx->applywalltime, ctx->applycputime);
+	}
+	ierr = VecRestoreArrayRead(rhs, &ba); CHKERRQ(ierr);
+	ierr = VecRestoreArray(x, &xa); CHKERRQ(ierr);
+	*reason = PCRICHARDSON_CONVERGED_ITS;
+	*outits = it;
+	return ierr;
+}
+
+PetscErrorCode setup_localpreconditioner_blasted(KSP ksp, Blasted_data *const bctx)
+{
+	Mat A;
+	PetscErrorCode ierr = KSPGetOperators(ksp, NULL, &A); CHKERRQ(ierr);
+	PetscInt matbs;
+	MatType mtype;
+	ierr = MatGetBlockSize(A, &matbs); CHKERRQ(ierr);
+	ierr = MatGetType(A, &mtype); CHKERRQ(ierr);
+	auto is = [&](const char *t) { return std::strcmp(mtype, t) == 0; };
+	const bool isblock = is(MATBAIJ) || is(MATMPIBAIJ) || is(MATSEQBAIJ);
+	const bool islocal = is(MATSEQAIJ) || is(MATSEQBAIJ);
+
+	PC pc;
+	ierr = KSPGetPC(ksp, &pc); CHKERRQ(ierr);
+	PetscBool isshell;
+	ierr = PetscObjectTypeCompare((PetscObject)pc, PCSHELL, &isshell); CHKERRQ(ierr);
+	if (!isshell)
+		SETERRQ(PETSC_COMM_WORLD, PETSC_ERR_ARG_WRONGSTATE, "Need SHELL preconditioner for BLASTed!\n");
+	if (!islocal)
+		SETERRQ(PETSC_COMM_WORLD, PETSC_ERR_SUP, "PC as PCSHELL is only supported for local solvers.");
+
+	bctx->bs = isblock ? (int)matbs : 1;
+	bctx->first_setup_done = false;
+	// know the type before deciding on the Richardson callback
+	{
+		char tstr[BLASTED_OPT_STRLEN];
+		PetscBool set = PETSC_FALSE;
+		PetscOptionsGetString(NULL, NULL, "-blasted_pc_type", tstr, BLASTED_OPT_STRLEN, &set);
+		bctx->prectype = BLASTED_NO_PREC;
+		if (set && bctx->bfactory)
+			bctx->prectype = ((const BlastedFactory *)bctx->bfactory)->solverTypeFromString(tstr);
+	}
+	ierr = PCShellSetContext(pc, (void *)bctx); CHKERRQ(ierr);
+	ierr = PCShellSetSetUp(pc, &compute_preconditioner_blasted); CHKERRQ(ierr);
+	ierr = PCShellSetApply(pc, &apply_local_blasted); CHKERRQ(ierr);
+	ierr = PCShellSetDestroy(pc, &cleanup_blasted); CHKERRQ(ierr);
+	if (bctx->prectype == BLASTED_SGS || bctx->prectype == BLASTED_GS) {
+		ierr = PCShellSetApplyRichardson(pc, &relax_local_blasted); CHKERRQ(ierr);
+	}
+	return ierr;
+}
+
+PetscErrorCode setup_blasted_stack(KSP ksp, Blasted_data_list *const bctx)
+{
+	BlastedFactory *factory = new SRFactory<double, int>();
+	bctx->bfactory = (void *)factory;
+	bctx->_defaultfactory = 1;
+	return setup_blasted_stack_ext(ksp, factory, bctx);
+}
+
+void computeTotalTimes(Blasted_data_list *const bctv)
+{
+	bctv->factorcputime = bctv->factorwalltime = bctv->applycputime = bctv->applywalltime = 0.0;
+	for (Blasted_data *node = bctv->ctxlist; node != NULL; node = node->next) {
+		bctv->factorwalltime += node->factorwalltime;
+		bctv->applywalltime += node->applywalltime;
+		bctv->factorcputime += node->factorcputime;
+		bctv->applycputime += node->applycputime;
+	}
+}
+
+}  // extern "C"
+
+int setup_blasted_stack_ext(KSP ksp, const BlastedFactory *const fctry, Blasted_data_list *const bctv)
+{
+	PC pc;
+	PetscErrorCode ierr = KSPGetPC(ksp, &pc); CHKERRQ(ierr);
+	auto is = [&](const char *type, PetscBool *flag) {
+		return PetscObjectTypeCompare((PetscObject)pc, type, flag);
+	};
+	PetscBool isbjacobi, isasm, isshell, ismg, isgamg, isksp;
+	ierr = is(PCBJACOBI, &isbjacobi); CHKERRQ(ierr);
+	ierr = is(PCASM, &isasm); CHKERRQ(ierr);
+	ierr = is(PCSHELL, &isshell); CHKERRQ(ierr);
+	ierr = is(PCMG, &ismg); CHKERRQ(ierr);
+	ierr = is(PCGAMG, &isgamg); CHKERRQ(ierr);
+	ierr = is(PCKSP, &isksp); CHKERRQ(ierr);
+
+	if (isbjacobi || isasm) {
+		ierr = KSPSetUp(ksp); CHKERRQ(ierr);
+		ierr = PCSetUp(pc); CHKERRQ(ierr);
+		PetscInt nlocal, first;
+		KSP *subksp;
+		if (isbjacobi) {
+			ierr = PCBJacobiGetSubKSP(pc, &nlocal, &first, &subksp); CHKERRQ(ierr);
+		} else {
+			ierr = PCASMGetSubKSP(pc, &nlocal, &first, &subksp); CHKERRQ(ierr);
+		}
+		if (nlocal != 1)
+			SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_WRONGSTATE, "Only one subdomain per rank is supported.");
+		ierr = setup_blasted_stack_ext(subksp[0], fctry, bctv); CHKERRQ(ierr);
+	} else if (ismg || isgamg) {
+		ierr = KSPSetUp(ksp); CHKERRQ(ierr);
+		ierr = PCSetUp(pc); CHKERRQ(ierr);
+		PetscInt nlevels;
+		ierr = PCMGGetLevels(pc, &nlevels); CHKERRQ(ierr);
+		for (PetscInt lvl = 1; lvl < nlevels; lvl++) {
+			KSP smoother;
+			ierr = PCMGGetSmoother(pc, lvl, &smoother); CHKERRQ(ierr);
+			ierr = setup_blasted_stack_ext(smoother, fctry, bctv); CHKERRQ(ierr);
+		}
+		KSP coarse;
+		ierr = PCMGGetCoarseSolve(pc, &coarse); CHKERRQ(ierr);
+		ierr = setup_blasted_stack_ext(coarse, fctry, bctv); CHKERRQ(ierr);
+	} else if (isksp) {
+		ierr = KSPSetUp(ksp); CHKERRQ(ierr);
+		ierr = PCSetUp(pc); CHKERRQ(ierr);
+		KSP sub;
+		ierr = PCKSPGetKSP(pc, &sub); CHKERRQ(ierr);
+		ierr = setup_blasted_stack_ext(sub, fctry, bctv); CHKERRQ(ierr);
+	} else if (isshell) {
+		std::printf("setup_blasted_stack(): Found valid parent KSP for BLASTed.\n");
+		appendBlastedDataContext(bctv, newBlastedDataContext());
+		bctv->ctxlist->bfactory = bctv->bfactory ? bctv->bfactory : (void *)fctry;
+		ierr = setup_localpreconditioner_blasted(ksp, bctv->ctxlist); CHKERRQ(ierr);
+	}
+	return ierr;
+}
+
+namespace blasted {
+int setup_blasted_stack_ext(KSP ksp, const FactoryBase<double, int> &factory, Blasted_data_list *const bctx)
+{
+	bctx->bfactory = (void *)&factory;
+	return ::setup_blasted_stack_ext(ksp, &factory, bctx);
+}
+}  // namespace blasted

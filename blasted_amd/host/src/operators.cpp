@@ -1,0 +1,397 @@
+// operators.cpp -- method bodies of blasted/operators.hpp: forwarding to the C ABI (blasted_hip.h).
+#include "blasted/operators.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "blasted_hip.h"
+#include "solvertypes.h"
+
+namespace blasted {
+
+const std::array<std::string, 6> PrecInfoList::descr = {
+    {"ILU-remainder", "Initial-ILU-rem", "Upper-min-diag-dom", "Upper-avg-diag-dom", "Lower-min-diag-dom",
+     "Lower-avg-diag-dom"}};
+const int PrecInfoList::field_width = 20;
+
+namespace detail {
+
+void HipOperator::check(const int rc)
+{
+	if (rc == BLASTED_HIP_OK)
+		return;
+	const std::string msg = blasted_hip_last_error();
+	if (rc == BLASTED_HIP_EINVAL || rc == BLASTED_HIP_ENOTIMPL)
+		throw std::invalid_argument("BLASTed(HIP): " + msg);
+	throw std::runtime_error("BLASTed(HIP): " + msg);
+}
+
+int HipOperator::default_device()
+{
+	// one operator per MPI rank (src/blasted_petsc.cpp:604-606): ranks of a node share its GPUs round-robin
+	static const char *const vars[] = {"BLASTED_HIP_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK",
+	                                   "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID",
+	                                   "LOCAL_RANK"};
+	const int ndev = blasted_hip_device_count();
+	if (ndev <= 0)
+		return 0;
+	for (const char *v : vars)
+		if (const char *e = std::getenv(v))
+			return std::atoi(e) % ndev;
+	return 0;
+}
+
+int HipOperator::sweep_mode()
+{
+	const char *e = std::getenv("BLASTED_HIP_SYNC_SWEEPS");
+	return (e && std::atoi(e) != 0) ? BLASTED_HIP_JACOBI_SYNC : BLASTED_HIP_ASYNC;
+}
+
+HipOperator::HipOperator() : h{nullptr}, pattern_set{false}
+{
+	check(blasted_hip_create(&h, default_device(), nullptr));
+}
+
+HipOperator::~HipOperator()
+{
+	if (h)
+		blasted_hip_destroy(h);
+}
+
+void HipOperator::bind(const CRawBSRMatrix<double, int> &mat, const int bs, const StorageOptions stor)
+{
+	if (!pattern_set) {
+		check(blasted_hip_set_pattern(h, mat.nbrows, mat.browptr[mat.nbrows], bs,
+		                              stor == RowMajor ? BLASTED_HIP_ROWMAJOR : BLASTED_HIP_COLMAJOR,
+		                              mat.browptr, mat.bcolind, mat.diagind, BLASTED_HIP_HOST));
+		pattern_set = true;
+	}
+	check(blasted_hip_set_values(h, mat.vals, BLASTED_HIP_HOST));
+}
+
+void *device_buffer_alloc(const std::size_t nbytes)
+{
+	void *p = nullptr;
+	HipOperator::check(blasted_hip_buffer_alloc(&p, nbytes, HipOperator::default_device()));
+	return p;
+}
+void device_buffer_free(void *dev)
+{
+	blasted_hip_buffer_free(dev);
+}
+void device_buffer_upload(void *dev, const void *host, const std::size_t nbytes)
+{
+	HipOperator::check(blasted_hip_buffer_upload(dev, host, nbytes));
+}
+void device_buffer_download(void *host, const void *dev, const std::size_t nbytes)
+{
+	HipOperator::check(blasted_hip_buffer_download(host, dev, nbytes));
+}
+
+}  // namespace detail
+
+using detail::HipOperator;
+
+// ------------------------------------------------------------------------------- matrix views
+
+template <typename scalar, typename index>
+SRMatrixView<scalar, index>::SRMatrixView(SRMatrixStorage<const scalar, const index> &&matrix,
+                                          const StorageType storagetype, const int block_size,
+                                          const StorageOptions layout)
+    : MatrixView<scalar, index>(storagetype), mat(std::move(matrix)), bs_{block_size},
+      op{new HipOperator()}
+{
+	const CRawBSRMatrix<scalar, index> raw(&mat.browptr[0], &mat.bcolind[0], &mat.vals[0], &mat.diagind[0],
+	                                       &mat.browendptr[0], mat.nbrows, mat.nnzb, mat.nbstored);
+	op->bind(raw, bs_, layout);
+}
+
+template <typename scalar, typename index>
+SRMatrixView<scalar, index>::~SRMatrixView()
+{
+}
+
+template <typename scalar, typename index>
+void SRMatrixView<scalar, index>::apply(const scalar *const x, scalar *const __restrict y) const
+{
+	HipOperator::check(blasted_hip_spmv(op->get(), x, y, BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index>
+void SRMatrixView<scalar, index>::apply_device(const scalar *const dx, scalar *const dy) const
+{
+	HipOperator::check(blasted_hip_spmv(op->get(), dx, dy, BLASTED_HIP_DEVICE));
+}
+
+template <typename scalar, typename index>
+void SRMatrixView<scalar, index>::gemv3(const scalar a, const scalar *const __restrict x, const scalar b,
+                                        const scalar *const y, scalar *const z) const
+{
+	HipOperator::check(blasted_hip_gemv3(op->get(), a, x, b, y, z, BLASTED_HIP_HOST));
+}
+
+template class SRMatrixView<double, int>;
+
+// ------------------------------------------------------------------------------- base classes
+
+template <typename scalar, typename index>
+SRPreconditioner<scalar, index>::SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix)
+    : Preconditioner<scalar, index>(SPARSEROW), pmat(std::move(matrix)),
+      mat(&pmat.browptr[0], &pmat.bcolind[0], &pmat.vals[0], &pmat.diagind[0], &pmat.browendptr[0],
+          pmat.nbrows, pmat.nnzb, pmat.nbstored)
+{
+}
+
+template <typename scalar, typename index>
+SRPreconditioner<scalar, index>::~SRPreconditioner()
+{
+}
+
+template <typename scalar, typename index>
+void SRPreconditioner<scalar, index>::apply_device(const scalar *const, scalar *const) const
+{
+	throw std::runtime_error("apply_device is not provided by this operator");
+}
+
+template <typename scalar, typename index>
+void SRPreconditioner<scalar, index>::apply_relax_device(const scalar *const, scalar *const) const
+{
+	throw std::runtime_error("apply_relax_device is not provided by this operator");
+}
+
+template <typename scalar, typename index>
+NoPreconditioner<scalar, index>::NoPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix,
+                                                  const index bs)
+    : SRPreconditioner<scalar, index>(std::move(matrix)), ndim{this->pmat.nbrows * bs}
+{
+}
+
+template <typename scalar, typename index>
+void NoPreconditioner<scalar, index>::apply(const scalar *const x, scalar *const __restrict y) const
+{
+	std::memcpy(y, x, sizeof(scalar) * (std::size_t)ndim);  // identity: nothing to offload
+}
+
+template <typename scalar, typename index>
+void NoPreconditioner<scalar, index>::apply_relax(const scalar *const, scalar *const __restrict) const
+{
+}
+
+template class SRPreconditioner<double, int>;
+template class NoPreconditioner<double, int>;
+
+// ------------------------------------------------------------------------------- (block-)Jacobi
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+BJacobiSRPreconditioner<scalar, index, bs, stor>::BJacobiSRPreconditioner(
+    SRMatrixStorage<const scalar, const index> &&matrix)
+    : SRPreconditioner<scalar, index>(std::move(matrix))
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+BJacobiSRPreconditioner<scalar, index, bs, stor>::~BJacobiSRPreconditioner()
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::bind_and_invert()
+{
+	if (!op)
+		op.reset(new HipOperator());
+	op->bind(mat, bs, stor);
+	HipOperator::check(blasted_hip_jacobi_compute(op->get()));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+PrecInfo BJacobiSRPreconditioner<scalar, index, bs, stor>::compute()
+{
+	bind_and_invert();
+	return PrecInfo();
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
+                                                             scalar *const __restrict z) const
+{
+	if (!op)
+		throw std::runtime_error("Jacobi preconditioner: apply() before compute()");
+	HipOperator::check(blasted_hip_jacobi_apply(op->get(), r, z, BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
+                                                                    scalar *const dz) const
+{
+	if (!op)
+		throw std::runtime_error("Jacobi preconditioner: apply() before compute()");
+	HipOperator::check(blasted_hip_jacobi_apply(op->get(), dr, dz, BLASTED_HIP_DEVICE));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const,
+                                                                   scalar *const __restrict) const
+{
+	throw std::runtime_error("Jacobi relaxation is not part of the MI355X backend (out of the hot path)");
+}
+
+// ------------------------------------------------------------------------------- (block-)SGS
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::AsyncBlockSGS_SRPreconditioner(
+    SRMatrixStorage<const scalar, const index> &&matrix, const int naswps, const ApplyInit apply_inittype,
+    const int threadchunksize)
+    : BJacobiSRPreconditioner<scalar, index, bs, stor>(std::move(matrix)), napplysweeps{naswps},
+      ainit{apply_inittype}, thread_chunk_size{threadchunksize}
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::~AsyncBlockSGS_SRPreconditioner()
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+PrecInfo AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::compute()
+{
+	this->bind_and_invert();  // Jacobi compute + ytemp, src/solverops_sgs.cpp:33-45
+	return PrecInfo();
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
+                                                                    scalar *const __restrict z) const
+{
+	if (!op)
+		throw std::runtime_error("SGS preconditioner: apply() before compute()");
+	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, napplysweeps, (int)ainit,
+	                                         HipOperator::sweep_mode(), BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
+                                                                           scalar *const dz) const
+{
+	if (!op)
+		throw std::runtime_error("SGS preconditioner: apply() before compute()");
+	HipOperator::check(blasted_hip_sgs_apply(op->get(), dr, dz, napplysweeps, (int)ainit,
+	                                         HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const b,
+                                                                          scalar *const __restrict x) const
+{
+	if (!op)
+		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
+	// maxits steps; tolerances are never checked for SGS (src/solverops_sgs.cpp:96-115)
+	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, HipOperator::sweep_mode(),
+	                                         BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax_device(const scalar *const db,
+                                                                                 scalar *const dx) const
+{
+	if (!op)
+		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
+	HipOperator::check(blasted_hip_sgs_relax(op->get(), db, dx, solveparams.maxits,
+	                                         HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+}
+
+// ------------------------------------------------------------------------------- (block-)ILU(0)
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::AsyncBlockILU0_SRPreconditioner(
+    SRMatrixStorage<const scalar, const index> &&matrix, const int nbuildswp, const int napplyswp,
+    const bool uscl, const int tcs, const FactInit finit, const ApplyInit ainit, const bool tf,
+    const bool ta, const bool comp_rem)
+    : SRPreconditioner<scalar, index>(std::move(matrix)), usescaling{uscl}, threadedfactor{tf},
+      threadedapply{ta}, nbuildsweeps{nbuildswp}, napplysweeps{napplyswp}, thread_chunk_size{tcs},
+      factinittype{finit}, applyinittype{ainit}, compute_remainder{comp_rem}
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::~AsyncBlockILU0_SRPreconditioner()
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+PrecInfo AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::compute()
+{
+	if (!op)
+		op.reset(new HipOperator());  // first-time setup, src/solverops_ilu0.cpp:190-196
+	op->bind(mat, bs, stor);
+	PrecInfo info;
+	// sequential variants (seqilu0 / sfilu0): sweep until stationary = the exact serial factorisation
+	const int sweeps = threadedfactor ? nbuildsweeps : BLASTED_SEQUENTIAL_SYMBOL;
+	HipOperator::check(blasted_hip_ilu0_factorize(op->get(), sweeps, (int)factinittype, usescaling ? 1 : 0,
+	                                              HipOperator::sweep_mode(),
+	                                              compute_remainder ? info.f_info.data() : nullptr));
+	return info;
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
+                                                                     scalar *const __restrict z) const
+{
+	if (!op)
+		throw std::runtime_error("ILU0 preconditioner: apply() before compute()");
+	if (applyinittype != INIT_A_ZERO && applyinittype != INIT_A_JACOBI)
+		throw std::runtime_error(" scalar_ilu0_apply: Invalid init type!");  // src/solverops_ilu0.cpp:125-126
+	const int sweeps = threadedapply ? napplysweeps : BLASTED_SEQUENTIAL_SYMBOL;
+	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, sweeps, (int)applyinittype,
+	                                          HipOperator::sweep_mode(), BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
+                                                                            scalar *const dz) const
+{
+	if (!op)
+		throw std::runtime_error("ILU0 preconditioner: apply() before compute()");
+	if (applyinittype != INIT_A_ZERO && applyinittype != INIT_A_JACOBI)
+		throw std::runtime_error(" scalar_ilu0_apply: Invalid init type!");
+	const int sweeps = threadedapply ? napplysweeps : BLASTED_SEQUENTIAL_SYMBOL;
+	HipOperator::check(blasted_hip_ilu0_apply(op->get(), dr, dz, sweeps, (int)applyinittype,
+	                                          HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const,
+                                                                           scalar *const __restrict) const
+{
+	throw std::runtime_error("ILU relaxation not implemented!");
+}
+
+// ------------------------------------------------------------------------------- instantiations
+// the reference builds bs = 4, 5 (column-major), 4 (row-major) plus BUILD_BLOCK_SIZE
+// (src/solverops_ilu0.cpp:385-395); the device kernels cover 1, 2, 3, 4, 5, 7, 8 in both layouts.
+
+#define BLASTED_INSTANTIATE(BS, STOR)                                      \
+	template class BJacobiSRPreconditioner<double, int, BS, STOR>;         \
+	template class AsyncBlockSGS_SRPreconditioner<double, int, BS, STOR>;  \
+	template class AsyncBlockILU0_SRPreconditioner<double, int, BS, STOR>;
+
+BLASTED_INSTANTIATE(1, ColMajor)
+BLASTED_INSTANTIATE(2, ColMajor)
+BLASTED_INSTANTIATE(3, ColMajor)
+BLASTED_INSTANTIATE(4, ColMajor)
+BLASTED_INSTANTIATE(5, ColMajor)
+BLASTED_INSTANTIATE(7, ColMajor)
+BLASTED_INSTANTIATE(8, ColMajor)
+BLASTED_INSTANTIATE(2, RowMajor)
+BLASTED_INSTANTIATE(3, RowMajor)
+BLASTED_INSTANTIATE(4, RowMajor)
+BLASTED_INSTANTIATE(5, RowMajor)
+BLASTED_INSTANTIATE(7, RowMajor)
+BLASTED_INSTANTIATE(8, RowMajor)
+
+template class JacobiSRPreconditioner<double, int>;
+template class AsyncSGS_SRPreconditioner<double, int>;
+template class AsyncILU0_SRPreconditioner<double, int>;
+
+}  // namespace blasted

@@ -93,7 +93,10 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 
 /* block_ilu0_apply, src/solverops_ilu0.cpp:55-148 ; scalar_ilu0_apply, :239-321.
  * z = S U^-1 L^-1 S r by napplysweeps lower sweeps then napplysweeps upper sweeps.
- * apply_init other than ZERO / JACOBI -> BLASTED_HIP_EINVAL (the reference throws, :125-126). */
+ * apply_init other than ZERO / JACOBI -> BLASTED_HIP_EINVAL (the reference throws, :125-126).
+ * A negative sweep count (BLASTED_SEQUENTIAL_SYMBOL) in factorize / apply selects the reference's
+ * sequential variants (threadedfactor / threadedapply = false): sweeps are repeated in place until one
+ * changes nothing, which is bit for bit the result of one in-order serial pass. */
 int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
                            int apply_init, int mode, int loc);
 
@@ -130,6 +133,13 @@ int blasted_hip_get_scale(blasted_hip_prec p, double *out_host);    /* nbrows*bs
 int blasted_hip_get_ytemp(blasted_hip_prec p, double *out_host);    /* nbrows*bs */
 /* device pointer of the factor storage (benchmarks: initialise in HBM without a host copy) */
 int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr);
+
+/* ---- raw HBM buffers: the storage behind device_vector<T> (include/device_container.hpp:19-20,
+ * which on this backend is the HIP buffer holder).  Synchronous copies on the given device. */
+int blasted_hip_buffer_alloc(void **dev_ptr, unsigned long nbytes, int device);
+int blasted_hip_buffer_free(void *dev_ptr);
+int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long nbytes);
+int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
 
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */
 /* When enabled every apply/relax/spmv/factor call brackets its sweep kernels with hipEvents on the

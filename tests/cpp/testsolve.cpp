@@ -1,0 +1,265 @@
+// testsolve.cpp -- native (no PETSc) end-to-end driver through the C++ operator API, the counterpart
+// of the reference's tests/testsolve.cpp + tests/solvers.cpp: read a Matrix-Market system, build the
+// preconditioner through SRFactory, solve with BiCGSTAB / Richardson whose matrix-vector products and
+// preconditioner applications run on the GPU, and compare with the known solution.
+// Same command-line option names as the reference driver (tests/testsolve.cpp:133-187).
+#undef NDEBUG
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "blockmatrices.hpp"
+#include "solverfactory.hpp"
+
+using namespace blasted;
+
+struct Params {
+	std::string solvertype = "bcgs", precontype = "jacobi", factinittype = "init_original",
+	            applyinittype = "init_zero", mattype = "csr", storageorder = "colmajor", mat_file, b_file,
+	            x_file = "NONE";
+	int blocksize = 4, maxiter = 1000, nbuildsweeps = 1, napplysweeps = 1, threadchunksize = 256;
+	double testtol = 1e-4, tol = 1e-6;
+};
+
+static Params parse(int argc, char **argv)
+{
+	Params p;
+	std::map<std::string, std::string> kv;
+	for (int i = 1; i + 1 < argc; i += 2) {
+		std::string k = argv[i];
+		if (k.rfind("--", 0) != 0) {
+			std::cerr << "bad option " << k << "\n";
+			std::exit(2);
+		}
+		kv[k.substr(2)] = argv[i + 1];
+	}
+	auto S = [&](const char *k, std::string &v) { if (kv.count(k)) v = kv[k]; };
+	auto I = [&](const char *k, int &v) { if (kv.count(k)) v = std::atoi(kv[k].c_str()); };
+	auto D = [&](const char *k, double &v) { if (kv.count(k)) v = std::atof(kv[k].c_str()); };
+	S("solver_type", p.solvertype); S("preconditioner_type", p.precontype);
+	S("fact_init_type", p.factinittype); S("apply_init_type", p.applyinittype);
+	S("mat_type", p.mattype); S("storage_order", p.storageorder);
+	S("mat_file", p.mat_file); S("b_file", p.b_file); S("x_file", p.x_file);
+	I("block_size", p.blocksize); I("max_iter", p.maxiter); I("build_sweeps", p.nbuildsweeps);
+	I("apply_sweeps", p.napplysweeps); I("thread_chunk_size", p.threadchunksize);
+	D("test_tol", p.testtol); D("solver_tol", p.tol);
+	return p;
+}
+
+static std::vector<double> read_dense(const std::string &path)
+{
+	std::ifstream f(path);
+	if (!f) { std::cerr << "cannot open " << path << "\n"; std::exit(2); }
+	std::string line;
+	std::getline(f, line);
+	while (std::getline(f, line) && line[0] == '%') {}
+	std::istringstream hs(line);
+	long nr, nc;
+	hs >> nr >> nc;
+	std::vector<double> v((size_t)(nr * nc));
+	for (auto &x : v) f >> x;
+	return v;
+}
+
+// general coordinate Matrix-Market -> sparse (block-)row storage with ascending block columns
+static SRMatrixStorage<double, int> read_bsr(const std::string &path, const int bs, const bool rowmajor)
+{
+	std::ifstream f(path);
+	if (!f) { std::cerr << "cannot open " << path << "\n"; std::exit(2); }
+	std::string line;
+	std::getline(f, line);
+	if (line.find("coordinate") == std::string::npos || line.find("general") == std::string::npos) {
+		std::cerr << "can only read general coordinate matrices\n";
+		std::exit(2);
+	}
+	while (std::getline(f, line) && line[0] == '%') {}
+	std::istringstream hs(line);
+	long nr, nc, nnz;
+	hs >> nr >> nc >> nnz;
+	assert(nr == nc && nr % bs == 0);
+	const int nb = (int)(nr / bs);
+	struct Ent { long key; int inblk; double v; };
+	std::vector<Ent> ents((size_t)nnz);
+	for (auto &e : ents) {
+		long i, j;
+		double v;
+		f >> i >> j >> v;
+		--i; --j;
+		const int r = (int)(i % bs), c = (int)(j % bs);
+		e.key = (i / bs) * nb + (j / bs);
+		e.inblk = rowmajor ? r * bs + c : c * bs + r;
+		e.v = v;
+	}
+	std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+	std::vector<long> keys;
+	for (const auto &e : ents)
+		if (keys.empty() || keys.back() != e.key) keys.push_back(e.key);
+	const int nnzb = (int)keys.size();
+	SRMatrixStorage<double, int> m;
+	m.nbrows = nb; m.nnzb = nnzb; m.nbstored = nnzb;
+	m.browptr.resize(nb + 1); m.bcolind.resize(nnzb); m.vals.resize(nnzb * bs * bs);
+	m.diagind.resize(nb); m.browendptr.resize(nb);
+	for (int i = 0; i < nnzb * bs * bs; i++) m.vals[i] = 0;
+	for (int i = 0; i <= nb; i++) m.browptr[i] = 0;
+	size_t k = 0;
+	for (int b = 0; b < nnzb; b++) {
+		const int brow = (int)(keys[b] / nb), bcol = (int)(keys[b] % nb);
+		m.bcolind[b] = bcol;
+		m.browptr[brow + 1]++;
+		if (brow == bcol) m.diagind[brow] = b;
+		while (k < ents.size() && ents[k].key == keys[b]) {
+			m.vals[b * bs * bs + ents[k].inblk] += ents[k].v;
+			k++;
+		}
+	}
+	for (int i = 0; i < nb; i++) {
+		m.browptr[i + 1] += m.browptr[i];
+		m.browendptr[i] = m.browptr[i + 1];
+	}
+	return m;
+}
+
+static double dot(const std::vector<double> &a, const std::vector<double> &b)
+{
+	double s = 0;
+	for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i];
+	return s;
+}
+
+struct SolveInfo { int iters; double relres; };
+
+// right-preconditioned BiCGSTAB, the algorithm of the reference's test solver (tests/solvers.cpp:140-239)
+static SolveInfo bicgstab(const SRMatrixView<double, int> &A, const Preconditioner<double, int> &M,
+                          const std::vector<double> &rhs, std::vector<double> &x, double tol, int maxiter)
+{
+	const size_t n = rhs.size();
+	std::vector<double> r(n), rhat(n), p(n, 0.0), v(n, 0.0), y(n), z(n), t(n);
+	double omega = 1, rhoold = 1, alpha = 1, resnorm = 100;
+	A.gemv3(-1.0, x.data(), 1.0, rhs.data(), r.data());
+	rhat = r;
+	const double bnorm = std::sqrt(dot(rhs, rhs));
+	int step = 0;
+	while (step < maxiter) {
+		const double rho = dot(rhat, r);
+		const double beta = rho * alpha / (rhoold * omega);
+		for (size_t i = 0; i < n; i++) p[i] = r[i] + beta * p[i] - beta * omega * v[i];
+		M.apply(p.data(), y.data());
+		A.apply(y.data(), v.data());
+		alpha = rho / dot(rhat, v);
+		for (size_t i = 0; i < n; i++) r[i] -= alpha * v[i];
+		M.apply(r.data(), z.data());
+		A.apply(z.data(), t.data());
+		omega = dot(t, r) / dot(t, t);
+		for (size_t i = 0; i < n; i++) {
+			x[i] += alpha * y[i] + omega * z[i];
+			r[i] -= omega * t[i];
+		}
+		resnorm = std::sqrt(dot(r, r));
+		if (resnorm / bnorm < tol) break;
+		rhoold = rho;
+		step++;
+	}
+	return {step + 1, resnorm / bnorm};
+}
+
+static SolveInfo richardson(const SRMatrixView<double, int> &A, const Preconditioner<double, int> &M,
+                            const std::vector<double> &rhs, std::vector<double> &x, double tol, int maxiter)
+{
+	const size_t n = rhs.size();
+	std::vector<double> s(n), d(n);
+	const double bnorm = std::sqrt(dot(rhs, rhs));
+	double rel = 1e300;
+	int step = 0;
+	while (step < maxiter) {
+		A.gemv3(-1.0, x.data(), 1.0, rhs.data(), s.data());
+		rel = std::sqrt(dot(s, s)) / bnorm;
+		if (rel < tol) break;
+		M.apply(s.data(), d.data());
+		for (size_t i = 0; i < n; i++) x[i] += d[i];
+		step++;
+	}
+	return {step, rel};
+}
+
+template <int bs>
+static int test_solve(const Params &params)
+{
+	const bool rm = params.storageorder == "rowmajor";
+	SRMatrixView<double, int> *mat = nullptr;
+	if (bs == 1)
+		mat = new CSRMatrixView<double, int>(move_to_const<double, int>(read_bsr(params.mat_file, 1, false)));
+	else if (rm)
+		mat = new BSRMatrixView<double, int, bs, RowMajor>(move_to_const<double, int>(read_bsr(params.mat_file, bs, true)));
+	else
+		mat = new BSRMatrixView<double, int, bs, ColMajor>(move_to_const<double, int>(read_bsr(params.mat_file, bs, false)));
+	SRMatrixStorage<const double, const int> cmat = move_to_const<double, int>(read_bsr(params.mat_file, bs, rm));
+	const std::vector<double> b = read_dense(params.b_file);
+	std::printf("Read matrix with %d (block-)rows, %d nonzero blocks, block size %d\n", cmat.nbrows, cmat.nnzb, bs);
+
+	SRFactory<double, int> fctry;
+	AsyncSolverSettings aparams;
+	aparams.scale = false;
+	aparams.nbuildsweeps = params.nbuildsweeps;
+	aparams.napplysweeps = params.napplysweeps;
+	aparams.thread_chunk_size = params.threadchunksize;
+	aparams.bs = bs;
+	aparams.prectype = fctry.solverTypeFromString(params.precontype);
+	aparams.fact_inittype = getFactInitFromString(params.factinittype);
+	aparams.apply_inittype = getApplyInitFromString(params.applyinittype);
+	aparams.blockstorage = rm ? RowMajor : ColMajor;
+	aparams.relax = false;
+	aparams.compute_precinfo = false;
+
+	SRPreconditioner<double, int> *prec = fctry.create_preconditioner(std::move(cmat), aparams);
+	prec->compute();
+
+	std::vector<double> x(mat->dim(), 0.0);
+	SolveInfo info;
+	if (params.solvertype == "richardson")
+		info = richardson(*mat, *prec, b, x, params.tol, params.maxiter);
+	else if (params.solvertype == "bcgs")
+		info = bicgstab(*mat, *prec, b, x, params.tol, params.maxiter);
+	else {
+		std::cerr << " ! Invalid solver option!\n";
+		std::abort();
+	}
+	std::printf(" Num iters = %d, final rel res = %g\n", info.iters, info.relres);
+	int rc = info.relres < params.tol ? 0 : 1;
+	if (params.x_file != "NONE") {
+		const std::vector<double> ans = read_dense(params.x_file);
+		double l2 = 0;
+		for (int i = 0; i < mat->dim(); i++) l2 += (x[i] - ans[i]) * (x[i] - ans[i]);
+		l2 = std::sqrt(l2);
+		std::printf(" L2 norm of error = %g\n", l2);
+		if (!(l2 < params.testtol)) rc = 1;
+	}
+	delete prec;
+	delete mat;
+	return rc;
+}
+
+int main(int argc, char **argv)
+{
+	const Params p = parse(argc, argv);
+	try {
+		if (p.mattype == "csr") return test_solve<1>(p);
+		switch (p.blocksize) {
+		case 3: return test_solve<3>(p);
+		case 4: return test_solve<4>(p);
+		case 5: return test_solve<5>(p);
+		case 7: return test_solve<7>(p);
+		default: std::cerr << "block size not built into the driver\n"; return 2;
+		}
+	} catch (const std::exception &e) {
+		std::cerr << "exception: " << e.what() << "\n";
+		return 3;
+	}
+}

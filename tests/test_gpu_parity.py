@@ -396,3 +396,30 @@ def test_medium_poisson_64_against_oracle():
     za = p.ilu0_apply(r, 3, mode=capi.ASYNC)
     assert np.abs(za - exact).max() <= np.abs(z - exact).max() * 1.0001
     p.close()
+
+
+# ---------------------------------------------------------------------------- sequential variants
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "msc_csr", "poisson16_bs4", "poisson12_bs5", "random_bs4"])
+def test_sequential_variants_are_exact(golden, case):
+    """seqilu0 / sfilu0 / sapilu0 (threadedfactor / threadedapply = false, or -blasted_async_sweeps -1):
+    a negative sweep count sweeps until stationary = one in-order serial pass of the reference."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ORIGINAL)["iluvals"]
+    p = make_prec(m)
+    p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL)
+    gf = p.get_iluvals()
+    assert rel(gf, exact) < TOL_EXACT
+    # bitwise fixed point: more sweeps do not change a single bit
+    p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL)
+    assert np.array_equal(p.get_iluvals(), gf)
+    z = p.ilu0_apply(r, -1, init=capi.INIT_A_ZERO)
+    assert rel(z, O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL)) < TOL_EXACT
+    z2 = p.ilu0_apply(r, -1, init=capi.INIT_A_JACOBI)
+    assert np.array_equal(z, z2)  # the stationary point does not depend on the initial guess
+    p.jacobi_compute()
+    zs = p.sgs_apply(r, -1, init=capi.INIT_A_ZERO)
+    assert rel(zs, O.sgs_apply(m, p.get_dblocks(), r, 1, mode=O.GS_SERIAL)) < TOL_EXACT
+    p.close()
