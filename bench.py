@@ -45,7 +45,8 @@ def cpu_baseline(nsample, bs, sweeps, full_pair_bytes, budget_s=12.0):
     """The oracle's threaded port of the reference loop nest (omp for schedule(dynamic,256) nowait),
     timed on this box's host cores on a bounded sample of the same workload (nsample^3 instead of
     256^3), scaled to the metric's unit by algorithmic bytes."""
-    import numpy as np
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import oracle
     from blasted_amd import workloads
     m = workloads.poisson3d(nsample + 2, bs, grid="uniform")
@@ -65,6 +66,38 @@ def cpu_baseline(nsample, bs, sweeps, full_pair_bytes, budget_s=12.0):
                   "min of %d calls = %.1f ms; scaled to 256^3 by algorithmic bytes" %
                   (nsample, bs, sweeps, sweeps, reps, t * 1e3),
     }
+
+
+def max_over_ranks(seconds, device):
+    """Whole-job time = the slowest rank's time (all_reduce MAX; identity for a single process)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(world, units_per_step, steps, elapsed):
+    """Replicas only: every rank processes units_per_step * steps units of its own copy."""
+    return world * units_per_step * steps / elapsed
+
+
+def measured_copy_gbps(dev, nbytes=1 << 31, reps=5):
+    """Device copy bandwidth of this box (read + write bytes / time): the practical HBM ceiling the
+    roofline fraction can be read against (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)."""
+    import torch
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -155,14 +188,12 @@ def main():
     tm = p.get_timing(reset=True)
     p.set_timing(False)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = max_over_ranks(t1 - t0, dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * units_per_step * args.steps / elapsed
+        value = job_throughput(world, units_per_step, args.steps, elapsed)
+        copy_gbps = measured_copy_gbps(dev)
         kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic = None
@@ -184,6 +215,7 @@ def main():
             "achieved_gbps": unit_bytes * units_per_step / (ms_per_step * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                          "kernel": "sweep_kernel (%s sweep)" % ("descending/upper" if kernel == "upper" else "ascending/lower"),
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes,
                          "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),

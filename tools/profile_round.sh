@@ -1,0 +1,13 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun).  usage: tools/profile_round.sh <tag> [bench args]
+# Collects rocprofv3 kernel stats and, in separate passes, the HBM PMC counters for bench.py;
+# raw output under gpurun_out/prof_<tag>_*, summaries are made by tools/summarize_prof.py.
+set -e
+TAG=$1; shift
+OUT=/root/repo/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -- python3 /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}_stats.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/prof_${TAG}_fetch.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/prof_${TAG}_write.err
+tail -1 $OUT/prof_${TAG}_bench.json | cut -c1-400

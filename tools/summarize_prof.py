@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/prof_<tag>_* (tools/profile_round.sh) into profiles/<tag>_*.{csv,json}.
+HBM traffic per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE reports half
+the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return f[0] if f else None
+
+
+def main(tag, op="ilu_apply"):
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    stats = one("prof_%s_stats/*/*_kernel_stats.csv" % tag)
+    if stats:
+        rows = [r for r in csv.reader(open(stats))]
+        keep = [rows[0]] + [r for r in rows[1:] if "bhip::" in r[0]]
+        with open(os.path.join(prof, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
+            csv.writer(f).writerows(keep)
+    b = os.path.join(ROOT, "gpurun_out", "prof_%s_bench.json" % tag)
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(prof, "%s_bench.json" % tag))
+    pmc = {}
+    for name, pat in (("FETCH_SIZE", "prof_%s_fetch/*/*_counter_collection.csv"), ("WRITE_SIZE", "prof_%s_write/*/*_counter_collection.csv")):
+        f = one(pat % tag)
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "bhip::" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc.setdefault(k, {})[name + "_KB_avg"] = sum(v) / len(v)
+            pmc[k]["launches_" + name] = len(v)
+    for k, d in pmc.items():
+        if "FETCH_SIZE_KB_avg" in d and "WRITE_SIZE_KB_avg" in d:
+            d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_KB_avg"] + d["WRITE_SIZE_KB_avg"]) * 1024.0
+    json.dump(pmc, open(os.path.join(prof, "%s_pmc.json" % tag), "w"), indent=1)
+    # bench.py reads the dominant kernel's traffic from profiles/traffic.json
+    dom = [k for k in pmc if "sweep4_kernel<1, 1, 1" in k or "sweep_kernel<4, false, 1, 1, 1>" in k]
+    tf = os.path.join(prof, "traffic.json")
+    cur = json.load(open(tf)) if os.path.exists(tf) else {}
+    if dom and "hbm_bytes_per_launch" in pmc[dom[0]]:
+        cur[op] = {"kernel": dom[0], "hbm_bytes_per_launch": pmc[dom[0]]["hbm_bytes_per_launch"], "from": tag}
+        json.dump(cur, open(tf, "w"), indent=1)
+    print(json.dumps(pmc, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
