@@ -25,7 +25,7 @@ SYMBOLS = [
     "blasted_hip_gemv3", "blasted_hip_get_iluvals", "blasted_hip_get_dblocks", "blasted_hip_get_scale",
     "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
-    "blasted_hip_buffer_upload", "blasted_hip_buffer_download",
+    "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
 ]
 
 _lib = None
@@ -99,6 +99,11 @@ def _loc(a):
     if hasattr(a, "is_cuda"):
         return DEVICE if a.is_cuda else HOST
     raise TypeError("expected a numpy array or a torch tensor")
+
+
+def set_tuning(spec):
+    """Process-wide kernel-variant selection (measurements only)."""
+    _check(lib().blasted_hip_set_tuning(None if spec is None else spec.encode()))
 
 
 def device_count():

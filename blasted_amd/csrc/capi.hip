@@ -953,6 +953,13 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 	});
 }
 
+/* ---- tuning -------------------------------------------------------------------------------- */
+
+int blasted_hip_set_tuning(const char *spec)
+{
+	return guarded([&] { set_sweep4_variant(spec); });
+}
+
 /* ---- timing -------------------------------------------------------------------------------- */
 
 int blasted_hip_set_timing(blasted_hip_prec p, int enable)

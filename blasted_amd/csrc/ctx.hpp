@@ -84,6 +84,7 @@ void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream
 bool sweep_supported(int bs);
 // kernels_sweep4.hip (tuned bs=4 column-major path; false = not covered, use the generic family)
 bool launch_sweep4(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+void set_sweep4_variant(const char *spec);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,

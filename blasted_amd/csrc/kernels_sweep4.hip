@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 		jlo = s_rp[0];
 		jhi = s_rp[rc];
 	}
+	jlo = __builtin_amdgcn_readfirstlane(jlo);  // wave-uniform by construction: let the compiler know
+	jhi = __builtin_amdgcn_readfirstlane(jhi);
 	if (PART != PART_NONE) {
 		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
 		for (int k = tid; k < ncol; k += 256)
@@ -128,20 +130,32 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 	}
 	__syncthreads();
 
+	// Chunk-relative addressing: wave-uniform 64-bit bases (SGPRs) + 32-bit per-lane byte offsets, which
+	// halves the address registers and arithmetic of the hot loop.  (xin keeps the full base: column
+	// indices are not chunk-local; n*8 < 4 GiB is checked on the host.)
+	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * 16);
+	const char *const xbase = reinterpret_cast<const char *>(a.xin);
+	const char *const rbase = reinterpret_cast<const char *>(a.rhs + (long)r0 * 4);
+	const char *const sbase = reinterpret_cast<const char *>(a.rscale + (long)r0 * 4);
+	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * 16);
+	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * 4);
+
 	// Each pass of this loop handles UNR row steps.  All loads of the UNR steps (KFIX predicated block
 	// passes per row, straight-line) are issued before the first use, so one wave keeps UNR*KFIX 16-byte
 	// block loads plus as many x gathers in flight; rows with more than NB*KFIX blocks finish in a
 	// remainder loop.
-	constexpr int KFIX = (NB >= 4) ? 1 : 2;
+	// straight-line passes: 2*NB items cover a 7-point row's lower or diagonal+upper part; operators
+	// that visit the whole row (SpMV, relaxation) get twice as many
+	constexpr int KFIX = ((NB >= 4) ? 1 : 2) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
 	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
-		int irow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
+		int lrow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
 		bool ok[UNR];
 #pragma unroll
 		for (int u = 0; u < UNR; u++) {
 			const int ls = (step0 + u) * RSTEP + wave * RPW + g;  // position in sweep order
 			ok[u] = ls < rc;
 			const int lr = ok[u] ? (a.descending ? rc - 1 - ls : ls) : 0;
-			irow[u] = r0 + lr;
+			lrow[u] = lr;
 			const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1];
 			dgp[u] = s_dg[lr];
 			jbeg[u] = jend[u] = 0;
@@ -171,26 +185,28 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 				bv[u][k].y = 0.0;
 				xv[u][k] = 0.0;
 				if (PART != PART_NONE && jj < jend[u]) {
-					bv[u][k] = load_block16<NT>(a.vals + (long)jj * 16 + 2 * q);
+					bv[u][k] = load_block16<NT>(reinterpret_cast<const double *>(
+					    vbase + ((unsigned)(jj - jlo) * 128u + 16u * (unsigned)q)));
 					const bool isdiag = (jj == dgp[u]);
 					if (!((PART == PART_UPPER && DSRC == D_VALS_DIAG && isdiag) ||
 					      (PART == PART_OFFDIAG && isdiag))) {
 						const int cidx = jj - jlo;
 						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-						xv[u][k] = a.xin[(long)col * 4 + c];
+						xv[u][k] = *reinterpret_cast<const double *>(xbase + ((unsigned)col * 32u + 8u * (unsigned)c));
 					}
 				}
 			}
 			dv[u].x = 0.0;
 			dv[u].y = 0.0;
 			if (DSRC == D_DBLOCKS && ok[u] && slot == 0)
-				dv[u] = load_block16<false>(a.dvals + (long)irow[u] * 16 + 2 * q);
+				dv[u] = load_block16<false>(reinterpret_cast<const double *>(
+				    dbase + ((unsigned)lrow[u] * 128u + 16u * (unsigned)q)));
 			r2[u].x = r2[u].y = 0.0;
 			s2[u].x = s2[u].y = 1.0;
 			if (ok[u] && a.rhs) {
-				r2[u] = *reinterpret_cast<const double2_t *>(a.rhs + (long)irow[u] * 4 + 2 * h);
+				r2[u] = *reinterpret_cast<const double2_t *>(rbase + ((unsigned)lrow[u] * 32u + 16u * (unsigned)h));
 				if (a.rscale)
-					s2[u] = *reinterpret_cast<const double2_t *>(a.rscale + (long)irow[u] * 4 + 2 * h);
+					s2[u] = *reinterpret_cast<const double2_t *>(sbase + ((unsigned)lrow[u] * 32u + 16u * (unsigned)h));
 			}
 		}
 
@@ -216,10 +232,11 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 				for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
 					if (PART == PART_OFFDIAG && jj == dgp[u])
 						continue;
-					const double2_t v2 = load_block16<NT>(a.vals + (long)jj * 16 + 2 * q);
+					const double2_t v2 = load_block16<NT>(reinterpret_cast<const double *>(
+					    vbase + ((unsigned)(jj - jlo) * 128u + 16u * (unsigned)q)));
 					const int cidx = jj - jlo;
 					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					const double xc = a.xin[(long)col * 4 + c];
+					const double xc = *reinterpret_cast<const double *>(xbase + ((unsigned)col * 32u + 8u * (unsigned)c));
 					acc0 += v2.x * xc;
 					acc1 += v2.y * xc;
 				}
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 				double2_t o2;
 				o2.x = o0;
 				o2.y = o1;
-				double2_t *const dst = reinterpret_cast<double2_t *>(a.xout + (long)irow[u] * 4 + 2 * q);
+				double2_t *const dst = reinterpret_cast<double2_t *>(obase + ((unsigned)lrow[u] * 32u + 16u * (unsigned)q));
 				if (a.changed) {
 					const double2_t old = *dst;
 					if (!(old.x == o0) || !(old.y == o1))
@@ -278,21 +295,20 @@ __global__ __launch_bounds__(256) void sweep4_kernel(const SweepArgs a)
 }
 
 struct Variant {
-	int nb = 2, rchunk = 256, nt = 0, unr = 1, enabled = 1;
+	int nb = 2, rchunk = 128, nt = 1, unr = 2, enabled = 1;
 };
 
-static Variant parse_variant()
+static Variant parse_variant(const char *e)
 {
 	Variant v;
 	// BLASTED_HIP_SWEEP4 = "generic" | "nb<2|4>,r<128|256>,nt<0|1>,u<1|2|4>"   (tuning / A-B measurements)
-	const char *e = std::getenv("BLASTED_HIP_SWEEP4");
 	if (!e)
 		return v;
 	if (std::strcmp(e, "generic") == 0) {
 		v.enabled = 0;
 		return v;
 	}
-	int nb = 2, r = 256, nt = 0, unr = 1;
+	int nb = 2, r = 128, nt = 1, unr = 2;
 	if (std::sscanf(e, "nb%d,r%d,nt%d,u%d", &nb, &r, &nt, &unr) == 4) {
 		v.nb = nb;
 		v.rchunk = r;
@@ -302,13 +318,26 @@ static Variant parse_variant()
 	return v;
 }
 
+static Variant &current_variant()
+{
+	static Variant v = parse_variant(std::getenv("BLASTED_HIP_SWEEP4"));
+	return v;
+}
+
+// tuning hook behind blasted_hip_set_tuning(): same syntax as the BLASTED_HIP_SWEEP4 variable
+void set_sweep4_variant(const char *spec)
+{
+	current_variant() = parse_variant(spec);
+}
+
 template <int PART, int POST, int DSRC>
 static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 {
 #define BHIP_V(NBV, RV, NTV, UV)                                                                      \
 	if (v.nb == NBV && v.rchunk == RV && v.nt == NTV && v.unr == UV) {                                \
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + RV - 1) / RV);                         \
-		hipLaunchKernelGGL((sweep4_kernel<PART, POST, DSRC, NBV, RV, (NTV != 0), UV>), dim3(grid),     \
+		constexpr int UEFF = (PART == PART_ALL || PART == PART_OFFDIAG) ? 1 : UV; /* 4 passes: keep 8 waves */ \
+		hipLaunchKernelGGL((sweep4_kernel<PART, POST, DSRC, NBV, RV, (NTV != 0), UEFF>), dim3(grid),   \
 		                   dim3(256), 0, s, a);                                                       \
 		return true;                                                                                  \
 	}
@@ -316,8 +345,11 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 	BHIP_V(2, 256, 1, 1)
 	BHIP_V(2, 128, 0, 1)
 	BHIP_V(2, 128, 1, 1)
+	BHIP_V(2, 64, 1, 1)
+	BHIP_V(2, 64, 0, 1)
 	BHIP_V(2, 256, 0, 2)
 	BHIP_V(2, 128, 0, 2)
+	BHIP_V(2, 128, 1, 2)
 	BHIP_V(4, 256, 0, 1)
 	BHIP_V(4, 128, 0, 1)
 #undef BHIP_V
@@ -327,8 +359,12 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 // returns false when the tuned kernel does not cover the request (caller uses the generic family)
 bool launch_sweep4(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
-	static const Variant v = parse_variant();
+	const Variant &v = current_variant();
 	if (!v.enabled || a.pat.bs != 4 || a.pat.rowmajor || a.pat.nbrows == 0)
+		return false;
+	// 32-bit byte offsets: the vector must be below 4 GiB and a 256-row chunk of blocks below 4 GiB
+	// (33 M blocks; a matrix with such rows takes the generic family)
+	if ((long)a.pat.nbrows * 32 >= (1L << 32) || (long)a.pat.nnzb >= (1L << 25) * 7)
 		return false;
 	// 16-byte loads need 16-byte aligned arrays (hipMalloc gives 256; borrowed pointers are checked)
 	auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };

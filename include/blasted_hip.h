@@ -141,6 +141,11 @@ int blasted_hip_buffer_free(void *dev_ptr);
 int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long nbytes);
 int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
 
+/* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
+ * generic kernel family, or "nb<2|4>,r<128|256>,nt<0|1>,u<1|2>" for the tuned bs=4 kernel; the same
+ * strings are read once from the environment variable BLASTED_HIP_SWEEP4. */
+int blasted_hip_set_tuning(const char *spec);
+
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */
 /* When enabled every apply/relax/spmv/factor call brackets its sweep kernels with hipEvents on the
  * object's stream; nothing is synchronised until blasted_hip_get_timing.
