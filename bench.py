@@ -41,7 +41,7 @@ def algorithmic_bytes(n, bs):
     }
 
 
-def cpu_baseline(nsample, bs, sweeps, full_pair_bytes, budget_s=12.0):
+def cpu_baseline(op, nsample, bs, sweeps, full_unit_bytes, units_per_call, budget_s=12.0):
     """The oracle's threaded port of the reference loop nest (omp for schedule(dynamic,256) nowait),
     timed on this box's host cores on a bounded sample of the same workload (nsample^3 instead of
     256^3), scaled to the metric's unit by algorithmic bytes."""
@@ -50,21 +50,27 @@ def cpu_baseline(nsample, bs, sweeps, full_pair_bytes, budget_s=12.0):
     import oracle
     from blasted_amd import workloads
     m = workloads.poisson3d(nsample + 2, bs, grid="uniform")
-    f = oracle.ilu0_factorize(m, None, 1, mode=oracle.GS_SERIAL)["iluvals"]
     r = workloads.rhs_vector(m["nbrows"] * bs)
-    t1 = oracle.time_ilu0_apply(m, f, r, sweeps, 256, 2)
+    kw = {}
+    if op == "ilu_apply":
+        kw["iluvals"] = oracle.ilu0_factorize(m, None, 1, mode=oracle.GS_SERIAL)["iluvals"]
+    elif op == "factor":
+        kw["plist"] = oracle.ilu_positions(m)
+    elif op != "spmv":
+        kw["dblocks"] = oracle.jacobi_compute(m)
+    t1 = oracle.time_op(op, m, r, sweeps, 256, 2, **kw)
     reps = max(3, min(200, int(budget_s / max(t1, 1e-4))))
-    t = oracle.time_ilu0_apply(m, f, r, sweeps, 256, reps)
-    sample_bytes = algorithmic_bytes(nsample, bs)["ilu_pair"]
-    pairs_per_s_sample = sweeps / t
-    gbs = sample_bytes * sweeps / t / 1e9
+    t = oracle.time_op(op, m, r, sweeps, 256, reps, **kw)
+    ab = algorithmic_bytes(nsample, bs)
+    sample_unit = {"ilu_apply": ab["ilu_pair"], "sgs_apply": ab["sgs_pair"], "sgs_relax": 2 * ab["sgs_relax_pass"],
+                   "spmv": ab["spmv"], "factor": ab["factor_sweep"]}[op]
     return {
-        "value": pairs_per_s_sample * sample_bytes / full_pair_bytes,
+        "value": (units_per_call / t) * sample_unit / full_unit_bytes,
         "unit": "sweeps/s", "cores": oracle.num_threads(), "kind": "port",
-        "achieved_gbps": gbs,
-        "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) on Poisson %d^3 bs=%d, %d+%d sweeps, "
-                  "min of %d calls = %.1f ms; scaled to 256^3 by algorithmic bytes" %
-                  (nsample, bs, sweeps, sweeps, reps, t * 1e3),
+        "achieved_gbps": sample_unit * units_per_call / t / 1e9,
+        "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) %s on Poisson %d^3 bs=%d, %d sweeps per call, "
+                  "min of %d calls = %.1f ms; scaled to the full size by algorithmic bytes" %
+                  (op, nsample, bs, sweeps, reps, t * 1e3),
     }
 
 
@@ -224,7 +230,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, bs, s, ab["ilu_pair"])
+                out["cpu_baseline"] = cpu_baseline(args.op, args.cpu_sample_n, bs, s, unit_bytes, units_per_step)
             except Exception as e:  # the baseline is a reported side figure, never the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -53,7 +53,7 @@ def lib():
         _lib = C.CDLL(LIBPATH)
         _lib.blasted_hip_last_error.restype = C.c_char_p
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double
-        _lib.blasted_hip_create.argtypes = [C.POINTER(vp), ci, vp]
+        _lib.blasted_hip_create.argtypes = [C.POINTER(vp), ci, vp, ci]
         _lib.blasted_hip_destroy.argtypes = [vp]
         _lib.blasted_hip_synchronize.argtypes = [vp]
         _lib.blasted_hip_set_pattern.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci]
@@ -114,9 +114,12 @@ class Prec:
     """One blasted_hip_prec object.  Vectors may be float64 numpy arrays (host path) or float64 CUDA
     torch tensors (device path, stream-ordered)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=0, own_stream=False):
+        """stream: a hipStream_t handle as an int (0 = the null stream, which is torch's default
+        stream); own_stream=True lets the object create a private stream instead."""
         self._h = C.c_void_p(0)
-        _check(lib().blasted_hip_create(C.byref(self._h), int(device), C.c_void_p(stream or 0)))
+        _check(lib().blasted_hip_create(C.byref(self._h), int(device), C.c_void_p(int(stream or 0)),
+                                        int(bool(own_stream))))
         self._keep = []
         self.n = 0
 

@@ -252,7 +252,7 @@ int blasted_hip_device_count(void)
 	return n;
 }
 
-int blasted_hip_create(blasted_hip_prec *out, int device, void *stream)
+int blasted_hip_create(blasted_hip_prec *out, int device, void *stream, int own_stream)
 {
 	return guarded([&] {
 		if (!out)
@@ -266,12 +266,12 @@ int blasted_hip_create(blasted_hip_prec *out, int device, void *stream)
 		BHIP_CHECK(hipSetDevice(device));
 		auto *p = new blasted_hip_prec_s();
 		p->device = device;
-		if (stream) {
-			p->stream = (hipStream_t)stream;
-			p->own_stream = false;
-		} else {
+		if (own_stream) {
 			BHIP_CHECK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
 			p->own_stream = true;
+		} else {
+			p->stream = (hipStream_t)stream;  // NULL = the null stream
+			p->own_stream = false;
 		}
 		*out = p;
 	});

@@ -51,7 +51,7 @@ int HipOperator::sweep_mode()
 
 HipOperator::HipOperator() : h{nullptr}, pattern_set{false}
 {
-	check(blasted_hip_create(&h, default_device(), nullptr));
+	check(blasted_hip_create(&h, default_device(), nullptr, /*own_stream=*/1));
 }
 
 HipOperator::~HipOperator()

@@ -184,3 +184,89 @@ def poisson3d_device(n, bs, device, grid="uniform", chunk_rows=1 << 21):
 def rhs_vector_device(n, device):
     import torch
     return torch.sin(0.37 * torch.arange(n, dtype=torch.float64, device=device)) + 1.1
+
+
+# ----------------------------------------------------------------------------- config 4: unstructured
+
+_MASK63 = (1 << 63) - 1
+
+
+def _mix64(x):
+    """Counter-based pseudo-random bits (splitmix64-style finaliser on torch int64, wrap-around
+    arithmetic), identical on CPU and GPU: value = f(index), no generator state."""
+    import torch
+    x = (x ^ (x >> 30).bitwise_and(0x3FFFFFFFF)) * (-4658895280553007687)   # 0xBF58476D1CE4E5B9
+    x = (x ^ (x >> 27).bitwise_and(0x1FFFFFFFFF)) * (-7723592293110705685)  # 0x94D049BB133111EB
+    x = x ^ (x >> 31).bitwise_and(0x1FFFFFFFF)
+    return x
+
+
+def _uniform(idx, seed, lo, hi):
+    """Deterministic U(lo,hi) of an int64 index tensor."""
+    bits = _mix64(idx * 2 + seed * 7919 + 12345).bitwise_and((1 << 53) - 1)
+    return lo + (hi - lo) * (bits.to(__import__("torch").float64) / float(1 << 53))
+
+
+def unstructured_bsr(nside, bs=5, device="cpu", window=4096, seed=12345):
+    """BASELINE config 4 stand-in (the reference ships no large unstructured matrix):
+    a 15-point grid graph on nside^3 nodes (7-point star + the 8 body diagonals, <= 14 neighbours) whose
+    node numbering is shuffled inside windows of `window` consecutive nodes (mesh-like locality, no band
+    structure), symmetric pattern, sorted columns, counter-based pseudo-random block values:
+    off-diagonal blocks U(-1,1) * 0.8/(5*deg), diagonal block (1 + 0.1 r) delta_rc + U(-0.02,0.02),
+    so every scalar row is strictly diagonally dominant.  Returns torch tensors (column-major blocks)."""
+    import torch
+    dev = torch.device(device)
+    n = nside
+    nb = n ** 3
+    idx = torch.arange(nb, dtype=torch.int64, device=dev)
+    i, j, k = idx % n, (idx // n) % n, idx // (n * n)
+    # node renumbering: stable sort by (window id, random key)
+    key = (idx // window) * (1 << 40) + _mix64(idx + seed).bitwise_and((1 << 40) - 1)
+    order = torch.argsort(key)           # order[new] = old
+    perm = torch.empty_like(order)
+    perm[order] = idx                    # perm[old] = new
+    offs = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    offs += [(a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)]
+    rows, cols = [], []
+    for (a, b, c) in offs:
+        ii, jj, kk = i + a, j + b, k + c
+        ok = (ii >= 0) & (ii < n) & (jj >= 0) & (jj < n) & (kk >= 0) & (kk < n)
+        old_col = (ii + n * (jj + n * kk))[ok]
+        rows.append(perm[idx[ok]])
+        cols.append(perm[old_col])
+    rows = torch.cat(rows)
+    cols = torch.cat(cols)
+    keyrc = torch.sort(rows * nb + cols).values
+    rows, cols = keyrc // nb, keyrc % nb
+    nnzb = rows.numel()
+    counts = torch.bincount(rows, minlength=nb)
+    browptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    browptr[1:] = torch.cumsum(counts, 0)
+    pos = torch.arange(nnzb, dtype=torch.int64, device=dev)
+    diagind = pos[rows == cols]
+    assert diagind.numel() == nb
+    deg = (counts - 1).clamp(min=1).to(torch.float64)
+    bs2 = bs * bs
+    vals = torch.empty(nnzb * bs2, dtype=torch.float64, device=dev)
+    chunk = 1 << 22
+    e = torch.arange(bs2, dtype=torch.int64, device=dev)
+    r_of_e, c_of_e = e % bs, e // bs     # column-major
+    for p0 in range(0, nnzb, chunk):
+        p1 = min(nnzb, p0 + chunk)
+        blk = pos[p0:p1]
+        u = _uniform(blk[:, None] * bs2 + e[None, :], seed, -1.0, 1.0)
+        isd = (rows[p0:p1] == cols[p0:p1])[:, None]
+        off = u * (0.8 / (5.0 * deg[rows[p0:p1]]))[:, None]
+        dg = torch.where((r_of_e == c_of_e)[None, :], (1.0 + 0.1 * r_of_e.to(torch.float64))[None, :] + 0 * u,
+                         0.02 * u)
+        vals[p0 * bs2:p1 * bs2] = torch.where(isd, dg, off).reshape(-1)
+    return {"nbrows": nb, "nnzb": int(nnzb), "bs": bs, "rowmajor": False, "browptr": browptr.to(torch.int32),
+            "bcolind": cols.to(torch.int32), "diagind": diagind.to(torch.int32), "vals": vals}
+
+
+def to_numpy(m):
+    """Host copy of a matrix dict made of torch tensors."""
+    out = dict(m)
+    for k in ("browptr", "bcolind", "diagind", "vals"):
+        out[k] = m[k].detach().cpu().numpy()
+    return out

@@ -58,9 +58,12 @@ enum { BLASTED_HIP_INIT_A_ZERO = 0, BLASTED_HIP_INIT_A_JACOBI = 1, BLASTED_HIP_I
 const char *blasted_hip_last_error(void);
 int blasted_hip_device_count(void);
 
-/* Lifetime.  stream: a hipStream_t, or NULL to let the object create its own.
+/* Lifetime.  own_stream != 0: the object creates (and later destroys) a private non-blocking stream and
+ * `stream` is ignored.  own_stream == 0: all work goes to `stream`, a caller-owned hipStream_t; NULL is
+ * the device's default (null) stream -- what a framework that enqueues its own kernels there
+ * (e.g. torch's default stream) must pass so that both are ordered.
  * Replaces: construction/destruction of an SRPreconditioner (src/solverops_base.cpp:20-24). */
-int blasted_hip_create(blasted_hip_prec *out, int device, void *stream);
+int blasted_hip_create(blasted_hip_prec *out, int device, void *stream, int own_stream);
 int blasted_hip_destroy(blasted_hip_prec p);
 int blasted_hip_synchronize(blasted_hip_prec p);
 

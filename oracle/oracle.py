@@ -209,6 +209,44 @@ def diag_dominance(m, factor_vals):
 
 # --------------------------------------------------------------------- timing helper (cpu_baseline)
 
+def time_op(op, m, r, sweeps, chunk, repeats, iluvals=None, dblocks=None, plist=None):
+    """Times `repeats` calls of one operator in the reference's threaded form (ASYNC_OMP); returns the
+    minimum seconds per call.  op: ilu_apply | sgs_apply | sgs_relax | spmv | factor."""
+    import time
+    M = _Mat(m)
+    r = _f64(r)
+    z = np.zeros(M.n)
+    y = np.zeros(M.n)
+    L = lib()
+    if op == "ilu_apply":
+        ilu = _f64(iluvals)
+        call = lambda: L.orc_ilu0_apply(M.ref, _ptr(ilu), _ptr(None), _ptr(y), int(sweeps), int(chunk),
+                                        ASYNC_OMP, INIT_A_ZERO, _ptr(r), _ptr(z))
+    elif op == "sgs_apply":
+        d = _f64(dblocks)
+        call = lambda: L.orc_sgs_apply(M.ref, _ptr(d), _ptr(y), int(sweeps), int(chunk), ASYNC_OMP,
+                                       INIT_A_ZERO, _ptr(r), _ptr(z))
+    elif op == "sgs_relax":
+        d = _f64(dblocks)
+        call = lambda: L.orc_sgs_relax(M.ref, _ptr(d), int(sweeps), int(chunk), ASYNC_OMP, _ptr(r), _ptr(z))
+    elif op == "spmv":
+        call = lambda: L.orc_spmv(M.ref, _ptr(r), _ptr(z))
+    elif op == "factor":
+        posptr, lowerp, upperp = (_i32(p) for p in plist)
+        ilu = np.zeros(M.nvals)
+        call = lambda: L.orc_ilu0_factorize(M.ref, _ptr(posptr), _ptr(lowerp), _ptr(upperp), int(sweeps),
+                                            int(chunk), ASYNC_OMP, INIT_F_ORIGINAL, _ptr(ilu), _ptr(None),
+                                            _ptr(None))
+    else:
+        raise ValueError(op)
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        call()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
 def time_ilu0_apply(m, iluvals, r, napplysweeps, chunk, repeats):
     """Times `repeats` threaded apply calls (reference loop nest); returns seconds per call (min)."""
     import time

@@ -1,0 +1,186 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties
+against an independent torch (eager, gather + bmm + index_add) evaluation of the same sweeps:
+  config 2: 3-D Poisson 256^3, bs=4, async block-ILU(0) factor + apply
+  config 3: same matrix, async block-SGS relaxation
+  config 4: unstructured bs=5, ~2 M block-rows
+  config 5: bs=8, 10^6 block-rows
+The oracle cannot run these sizes in seconds; the oracle comparisons of the same kernels at small and
+medium sizes are in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from blasted_amd import capi, workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_part_matvec(m, vals, x, part, dblocks_mode=None):
+    """sum_{j in part(i)} A_ij x_j for every block-row, with plain torch ops (independent checker)."""
+    import torch
+    bs, nb, nnzb = m["bs"], m["nbrows"], m["nnzb"]
+    dev = vals.device
+    bp = m["browptr"].to(torch.int64)
+    dg = m["diagind"].to(torch.int64)
+    counts = bp[1:] - bp[:-1]
+    out = torch.zeros(nb, bs, dtype=torch.float64, device=dev)
+    xv = x.view(nb, bs)
+    chunk = 1 << 22
+    rows_all = torch.repeat_interleave(torch.arange(nb, device=dev), counts)
+    for p0 in range(0, nnzb, chunk):
+        p1 = min(nnzb, p0 + chunk)
+        rows = rows_all[p0:p1]
+        pos = torch.arange(p0, p1, device=dev)
+        d = dg[rows]
+        if part == "lower":
+            sel = pos < d
+        elif part == "upper":
+            sel = pos > d
+        elif part == "offdiag":
+            sel = pos != d
+        elif part == "diag":
+            sel = pos == d
+        else:
+            sel = torch.ones_like(pos, dtype=torch.bool)
+        blocks = vals[p0 * bs * bs:p1 * bs * bs].view(-1, bs, bs)  # column-major: [c][r]
+        cols = m["bcolind"][p0:p1].to(torch.int64)
+        xg = xv[cols]                                             # [nblk, bs] (index c)
+        contrib = torch.einsum("bcr,bc->br", blocks, xg)
+        out.index_add_(0, rows[sel], contrib[sel])
+        del rows, pos, d, sel, blocks, cols, xg, contrib
+    return out.reshape(-1)
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.fixture(scope="module")
+def poisson256():
+    import torch
+    dev = torch.device("cuda", 0)
+    m = W.poisson3d_device(256, 4, dev, grid="uniform")
+    r = W.rhs_vector_device(m["nbrows"] * 4, dev)
+    p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
+    p.set_matrix(m)
+    yield m, r, p
+    p.close()
+
+
+def test_config2_sizes_and_positions(poisson256):
+    m, r, p = poisson256
+    assert m["nbrows"] == 16777216 and m["nnzb"] == 117047296
+    import ctypes as C
+    capi._check(capi.lib().blasted_hip_ilu0_positions(p._h))
+    npairs = C.c_long(0)
+    capi._check(capi.lib().blasted_hip_ilu0_positions_size(p._h, C.byref(npairs)))
+    assert npairs.value == 3 * 256 ** 3 - 3 * 256 ** 2  # 50 135 040: only diagonal entries have pairs
+
+
+def test_config2_spmv_matches_torch(poisson256):
+    import torch
+    m, r, p = poisson256
+    y = p.spmv(r)
+    want = torch_part_matvec(m, m["vals"], r, "all")
+    assert relmax(y, want) < 1e-13
+    z = p.gemv3(-2.0, r, 0.5, y)
+    assert relmax(z, -2.0 * want + 0.5 * y) < 1e-13
+
+
+def test_config2_ilu_apply_sync_sweeps_match_torch(poisson256):
+    """With the un-factored matrix as 'factor' (0 build sweeps, INIT_F_ORIGINAL: iluvals = A with
+    inverted diagonal blocks) two synchronous sweeps per triangle are re-derived with torch."""
+    import torch
+    m, r, p = poisson256
+    p.ilu0_factorize(0, init=capi.INIT_F_ORIGINAL)
+    z = p.ilu0_apply(r, 2, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC)
+    A = m["vals"]
+    # lower: y1 = r - L*0 = r ; y2 = r - L y1
+    y2 = r - torch_part_matvec(m, A, r, "lower")
+    # upper with D = inverse of A's diagonal blocks: z1 = D y2 ; z2 = D (y2 - U z1)
+    nb = m["nbrows"]
+    dblk = A.view(-1, 4, 4)[m["diagind"].to(torch.int64)]          # [nb][c][r]
+    dinv = torch.linalg.inv(dblk.transpose(1, 2))                   # math layout [r][c]
+    z1 = torch.einsum("brc,bc->br", dinv, y2.view(nb, 4)).reshape(-1)
+    t = y2 - torch_part_matvec(m, A, z1, "upper")
+    z2 = torch.einsum("brc,bc->br", dinv, t.view(nb, 4)).reshape(-1)
+    assert relmax(z, z2) < 1e-12
+    # linearity of the synchronous apply
+    r2 = torch.cos(0.11 * torch.arange(r.numel(), dtype=torch.float64, device=r.device))
+    za = p.ilu0_apply(r2, 2, mode=capi.JACOBI_SYNC)
+    zc = p.ilu0_apply(2.0 * r - 3.0 * r2, 2, mode=capi.JACOBI_SYNC)
+    assert relmax(zc, 2.0 * z - 3.0 * za) < 1e-12
+
+
+def test_config2_async_factor_and_apply_properties(poisson256):
+    """3 async build sweeps + async apply at full size: finite, remainder far below the initial one, and
+    the async apply lies between the synchronous iterate and the converged solve."""
+    import torch
+    m, r, p = poisson256
+    info = p.ilu0_factorize(3, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC, compute_info=True)
+    assert np.isfinite(info).all() and info[0] < 1e-3 * info[1]
+    zs = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+    za = p.ilu0_apply(r, 3, mode=capi.ASYNC)
+    zlong = p.ilu0_apply(r, 40, mode=capi.ASYNC)
+    assert torch.isfinite(za).all()
+    es, ea = float((zs - zlong).abs().max()), float((za - zlong).abs().max())
+    assert ea <= es * 1.0001
+
+
+def test_config3_sgs_relaxation_matches_torch(poisson256):
+    import torch
+    m, r, p = poisson256
+    p.jacobi_compute()
+    nb = m["nbrows"]
+    A = m["vals"]
+    dblk = A.view(-1, 4, 4)[m["diagind"].to(torch.int64)]
+    dinv = torch.linalg.inv(dblk.transpose(1, 2))
+    x = torch.zeros_like(r)
+    p.sgs_relax(r, x, 1, mode=capi.JACOBI_SYNC)  # ascending pass then descending pass, synchronous
+    x1 = torch.einsum("brc,bc->br", dinv, r.view(nb, 4)).reshape(-1)
+    t = r - torch_part_matvec(m, A, x1, "offdiag")
+    x2 = torch.einsum("brc,bc->br", dinv, t.view(nb, 4)).reshape(-1)
+    assert relmax(x, x2) < 1e-12
+    # config 3: async relaxation, 5 steps: the residual keeps decreasing (slowly: the right-hand side has
+    # a smooth component that SGS on a 256^3 Poisson grid damps slowly)
+    x = torch.zeros_like(r)
+    p.sgs_relax(r, x, 1, mode=capi.ASYNC)
+    res1 = float((r - p.spmv(x)).norm() / r.norm())
+    p.sgs_relax(r, x, 4, mode=capi.ASYNC)
+    res5 = float((r - p.spmv(x)).norm() / r.norm())
+    assert res5 < res1 < 1.0
+
+
+@pytest.mark.parametrize("cfg", ["config4_unstructured_bs5", "config5_poisson100_bs8"])
+def test_config4_config5(cfg):
+    import torch
+    dev = torch.device("cuda", 0)
+    if cfg.startswith("config4"):
+        m = W.unstructured_bsr(126, 5, device=dev)      # 2 000 376 block-rows
+        assert 1.9e6 < m["nbrows"] < 2.1e6
+    else:
+        m = W.poisson3d_device(100, 8, dev, grid="uniform")
+        assert m["nbrows"] == 1000000
+    bs, nb = m["bs"], m["nbrows"]
+    r = W.rhs_vector_device(nb * bs, dev)
+    p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
+    p.set_matrix(m)
+    A = m["vals"]
+    assert relmax(p.spmv(r), torch_part_matvec(m, A, r, "all")) < 1e-13
+    p.ilu0_factorize(0, init=capi.INIT_F_ORIGINAL)
+    z = p.ilu0_apply(r, 2, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC)
+    y2 = r - torch_part_matvec(m, A, r, "lower")
+    dblk = A.view(-1, bs, bs)[m["diagind"].to(torch.int64)]
+    dinv = torch.linalg.inv(dblk.transpose(1, 2))
+    z1 = torch.einsum("brc,bc->br", dinv, y2.view(nb, bs)).reshape(-1)
+    t = y2 - torch_part_matvec(m, A, z1, "upper")
+    z2 = torch.einsum("brc,bc->br", dinv, t.view(nb, bs)).reshape(-1)
+    assert relmax(z, z2) < 1e-11
+    # async factor + apply: converges to a fixed point (one more sweep changes nothing)
+    nsw = 40 if cfg.startswith("config4") else 300
+    info = p.ilu0_factorize(nsw, mode=capi.ASYNC, compute_info=True)
+    assert np.isfinite(info).all() and info[0] < 1e-10 * info[1]
+    za = p.ilu0_apply(r, nsw, mode=capi.ASYNC)
+    zb = p.ilu0_apply(r, nsw + 1, mode=capi.ASYNC)
+    assert relmax(za, zb) < 1e-12
+    p.close()
