@@ -957,7 +957,12 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 
 int blasted_hip_set_tuning(const char *spec)
 {
-	return guarded([&] { set_sweep4_variant(spec); });
+	return guarded([&] {
+		if (spec && std::strncmp(spec, "factor4=", 8) == 0)
+			set_factor4_enabled(spec[8] != '0');
+		else
+			set_sweep4_variant(spec);
+	});
 }
 
 /* ---- timing -------------------------------------------------------------------------------- */

@@ -85,6 +85,9 @@ bool sweep_supported(int bs);
 // kernels_sweep4.hip (tuned bs=4 column-major path; false = not covered, use the generic family)
 bool launch_sweep4(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweep4_variant(const char *spec);
+// kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
+bool launch_factor4(const FactorArgs &a, hipStream_t s);
+void set_factor4_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,

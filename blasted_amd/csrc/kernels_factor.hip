@@ -388,6 +388,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 {
 	if (a.pat.nbrows == 0)
 		return;
+	if (launch_factor4(a, s))
+		return;
 	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
 		hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, false>), dim3(grid), dim3(256), 0, s, a,

@@ -27,7 +27,10 @@ def main():
     p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
     p.set_matrix(m)
     ab = bench.algorithmic_bytes(a.n, 4)
-    if a.op == "ilu_apply":
+    if a.op == "factor":
+        step = lambda: p.ilu0_factorize(3)
+        lb, ub = ab["factor_sweep"], 0
+    elif a.op == "ilu_apply":
         p.ilu0_factorize(3)
         step = lambda: p.ilu0_apply(r, 3, out=z)
         lb, ub = ab["lower_sweep"], ab["upper_sweep"]
