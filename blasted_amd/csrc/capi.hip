@@ -361,7 +361,7 @@ int blasted_hip_set_pattern(blasted_hip_prec p, int nbrows, int nnzb, int bs, in
 			pat.bcolind = p->bcolind_own;
 			pat.diagind = p->diagind_own;
 		}
-		const int flags = validate_pattern_device(pat, p->stream);
+		const int flags = validate_pattern_device(pat, p->stream, &pat.max_row_len);
 		if (flags) {
 			std::string msg = "set_pattern: invalid sparse-row pattern:";
 			if (flags & 8) msg += " [browptr not monotone / wrong nnzb]";
@@ -961,7 +961,7 @@ int blasted_hip_set_tuning(const char *spec)
 		if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else
-			set_sweep4_variant(spec);
+			set_sweepw_variant(spec);
 	});
 }
 

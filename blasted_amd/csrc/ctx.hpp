@@ -53,6 +53,7 @@ enum DSrc {
 
 struct Pattern {
 	int nbrows = 0, nnzb = 0, bs = 0, rowmajor = 0;
+	int max_row_len = 0;  // longest block-row (set by set_pattern's validation pass)
 	const int *browptr = nullptr, *bcolind = nullptr, *diagind = nullptr;
 };
 
@@ -82,9 +83,9 @@ struct FactorArgs {
 // kernels_sweep.hip
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 bool sweep_supported(int bs);
-// kernels_sweep4.hip (tuned bs=4 column-major path; false = not covered, use the generic family)
-bool launch_sweep4(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
-void set_sweep4_variant(const char *spec);
+// kernels_sweepw.hip (tuned bs=4/8 column-major path; false = not covered, use the generic family)
+bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+void set_sweepw_variant(const char *spec);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);
@@ -101,7 +102,7 @@ void run_diag_dominance(const Pattern &pat, const double *fvals, double *dev_scr
 // kernels_aux.hip
 long run_ilu_positions(const Pattern &pat, int **posptr, int **lowerp, int **upperp, hipStream_t s);
 void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s);
-int validate_pattern_device(const Pattern &pat, hipStream_t s);
+int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len);
 
 struct Timing {
 	struct Rec {

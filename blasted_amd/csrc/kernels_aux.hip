@@ -173,6 +173,8 @@ __global__ void validate_kernel(const Pattern pat, int *flags)
 		return;
 	int f = 0;
 	const int b = pat.browptr[i], e = pat.browptr[i + 1];
+	if (e > b)
+		atomicMax(flags + 1, e - b);
 	if (b > e || b < 0 || e > pat.nnzb)
 		f |= 8;
 	else {
@@ -195,26 +197,28 @@ __global__ void validate_kernel(const Pattern pat, int *flags)
 		atomicOr(flags, f);
 }
 
-int validate_pattern_device(const Pattern &pat, hipStream_t s)
+int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len)
 {
 	int *flags = nullptr;
-	BHIP_CHECK(hipMalloc(&flags, sizeof(int)));
-	int h = 0;
+	BHIP_CHECK(hipMalloc(&flags, 2 * sizeof(int)));
+	int h[2] = {0, 0};
 	try {
-		BHIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
+		BHIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), s));
 		const unsigned grid = (unsigned)((pat.nbrows + 255) / 256);
 		if (grid) {
 			hipLaunchKernelGGL(validate_kernel, dim3(grid), dim3(256), 0, s, pat, flags);
 			BHIP_CHECK(hipGetLastError());
 		}
-		BHIP_CHECK(hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipMemcpyAsync(h, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
 		BHIP_CHECK(hipStreamSynchronize(s));
 	} catch (...) {
 		(void)hipFree(flags);
 		throw;
 	}
 	BHIP_CHECK(hipFree(flags));
-	return h;
+	if (max_row_len)
+		*max_row_len = h[1];
+	return h[0];
 }
 
 }  // namespace bhip

@@ -182,7 +182,7 @@ bool sweep_supported(int bs)
 
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
-	if (launch_sweep4(a, part, post, dsrc, s))
+	if (launch_sweepw(a, part, post, dsrc, s))
 		return;
 	switch (a.pat.bs) {
 	case 1: dispatch_layout<1>(a, part, post, dsrc, s); break;

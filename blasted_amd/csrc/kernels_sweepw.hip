@@ -1,0 +1,432 @@
+// kernels_sweepw.hip -- the tuned ("wide") row-sweep kernel for column-major blocks of size 4 and 8:
+// bs = 4 is the PETSc BAIJ layout of BASELINE.json's headline configuration
+// (src/blasted_petsc.cpp:256), bs = 8 its config 5.  Same operators and the same arithmetic as the
+// generic family in kernels_sweep.hip (see the table there); what differs is the data movement:
+//
+//  * a workgroup owns RCHUNK consecutive block-rows of the sweep; browptr / diagind and the bcolind
+//    range of the whole chunk are read from HBM once, coalesced, into LDS, so no value load waits on
+//    an index load from memory (the dependent chain per row is LDS -> {block, x segment} -> result);
+//  * a block is read as 16 bytes per lane (global_load_dwordx4) by LPB = bs*bs/2 lanes: lane q holds
+//    entries (2q, 2q+1) = rows 2h, 2h+1 of column c, with h = q % (bs/2), c = q / (bs/2); NB = 2 block
+//    slots per row are in flight per load instruction (bs=4: 4 rows per wave, bs=8: one);
+//  * all loads of a row step -- KFIX predicated block passes, straight-line, times UNR steps -- are
+//    issued before the first use; rows with more blocks finish in a remainder loop;
+//  * the x segment of a block is gathered as one double per lane (its column's entry); the mat-vec is
+//    two FMAs per lane plus an all-reduce over the column bits and the block-slot bit done on the VALU:
+//    DPP row rotations inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across rows (the LDS
+//    pipe only serves the staged indices);
+//  * the inverted diagonal block needed by the upper solve sits directly in front of the row's upper
+//    blocks in memory and is fetched by the same load instruction as block slot 0;
+//  * rhs is read and the result written as 16 bytes per lane (bs*8 contiguous bytes per row);
+//  * wave-uniform 64-bit bases + 32-bit per-lane byte offsets (halves address registers/arithmetic);
+//  * XCD-aware chunk numbering: each XCD sweeps one contiguous range of rows.
+#include "ctx.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace bhip {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned xcd_chunkw(unsigned bid, unsigned nwg)
+{
+	const unsigned xcd = bid & 7u, local = bid >> 3;
+	const unsigned base = nwg >> 3, rem = nwg & 7u;
+	return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+
+template <bool NT>
+__device__ __forceinline__ double2_t load_block16(const double *p)
+{
+	if (NT)
+		return __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p));
+	return *reinterpret_cast<const double2_t *>(p);
+}
+
+// ---- cross-lane sums on the VALU
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(const double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+// sum of the value with its partner 16 lanes away (lane ^ 16), in every lane
+__device__ __forceinline__ double xor16_sum(const double v)
+{
+	typedef unsigned v2u __attribute__((ext_vector_type(2)));
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const v2u a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+	const v2u b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
+// ... 32 lanes away (lane ^ 32)
+__device__ __forceinline__ double xor32_sum(const double v)
+{
+	typedef unsigned v2u __attribute__((ext_vector_type(2)));
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const v2u a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+	const v2u b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
+// All-reduce over lane bits [LOBIT, HIBIT) (HIBIT <= 6), every other bit kept.  Inside a 16-lane DPP row
+// the rotations row_ror 8, 4, 2 applied in this order sum bits 3, 2, 1: after each step the value is
+// periodic in the bit just summed, so the wrap-around of the next rotation lands on an equal value.
+template <int LOBIT, int HIBIT>
+__device__ __forceinline__ double allreduce_bits(double v)
+{
+	if (LOBIT <= 3 && HIBIT > 3)
+		v += dpp_mov<0x128>(v);  // row_ror:8
+	if (LOBIT <= 2 && HIBIT > 2)
+		v += dpp_mov<0x124>(v);  // row_ror:4
+	if (LOBIT <= 1 && HIBIT > 1)
+		v += dpp_mov<0x122>(v);  // row_ror:2
+	if (LOBIT <= 4 && HIBIT > 4)
+		v = xor16_sum(v);
+	if (LOBIT <= 5 && HIBIT > 5)
+		v = xor32_sum(v);
+	return v;
+}
+
+template <int BS>
+struct WGeo {
+	static constexpr int HB = BS / 2;         // lanes per block column
+	static constexpr int LPB = BS * HB;       // lanes per block (16 bytes each)
+	static constexpr int NB = 2;              // block slots per row
+	static constexpr int G = LPB * NB;        // lanes per block-row: 16 (bs=4), 64 (bs=8)
+	static constexpr int RPW = 64 / G;        // rows per wave and step
+	static constexpr int RSTEP = 4 * RPW;     // rows per workgroup and step
+	static constexpr int HBITS = HB == 2 ? 1 : 2;
+	static constexpr int GBITS = G == 16 ? 4 : 6;
+	static constexpr int BLKBYTES = BS * BS * 8;
+	static constexpr int ROWBYTES = BS * 8;
+};
+
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR>
+__global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
+{
+	using Ge = WGeo<BS>;
+	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
+	constexpr int CAP = 8 * RCHUNK;  // staged column indices
+	static_assert(BS == 4 || BS == 8, "wide kernel: bs 4 or 8");
+	static_assert(RCHUNK % (RSTEP * UNR) == 0, "chunk must be a multiple of the unrolled step");
+
+	__shared__ int s_rp[RCHUNK + 1];
+	__shared__ int s_dg[RCHUNK];
+	__shared__ int s_col[CAP];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int g = lane / G, t = lane % G;
+	const int slot = t / LPB, q = t % LPB;
+	const int c = q / HB, h = q % HB;  // column of this lane's two entries, row pair (2h, 2h+1)
+
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_chunkw(blockIdx.x, gridDim.x);
+	// rows of this chunk in index order: [r0, r0 + rc)
+	const long lin0 = (long)chunk * RCHUNK;
+	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
+	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;
+
+	for (int k = tid; k <= rc; k += 256)
+		s_rp[k] = a.pat.browptr[r0 + k];
+	for (int k = tid; k < rc; k += 256)
+		s_dg[k] = a.pat.diagind[r0 + k];
+	__syncthreads();
+	// column indices the chunk needs
+	int jlo, jhi;
+	if (PART == PART_LOWER) {
+		jlo = s_rp[0];
+		jhi = s_dg[rc - 1];
+	} else if (PART == PART_UPPER) {
+		jlo = s_dg[0];
+		jhi = s_rp[rc];
+	} else {
+		jlo = s_rp[0];
+		jhi = s_rp[rc];
+	}
+	jlo = __builtin_amdgcn_readfirstlane(jlo);  // wave-uniform by construction: let the compiler know
+	jhi = __builtin_amdgcn_readfirstlane(jhi);
+	if (PART != PART_NONE) {
+		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
+		for (int k = tid; k < ncol; k += 256)
+			s_col[k] = a.pat.bcolind[jlo + k];
+	}
+	__syncthreads();
+
+	// Chunk-relative addressing: wave-uniform 64-bit bases (SGPRs) + 32-bit per-lane byte offsets.  The
+	// host checks that a chunk's blocks and the whole vector stay below 4 GiB (launch_sweepw).
+	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * (BS * BS));
+	const char *const xbase = reinterpret_cast<const char *>(a.xin);
+	const char *const rbase = reinterpret_cast<const char *>(a.rhs + (long)r0 * BS);
+	const char *const sbase = reinterpret_cast<const char *>(a.rscale + (long)r0 * BS);
+	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * (BS * BS));
+	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * BS);
+
+	// straight-line passes: 2*NB items cover a 7-point row's lower or diagonal+upper part; operators
+	// that visit the whole row (SpMV, relaxation) get twice as many
+	constexpr int KFIX = 2 * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
+
+	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
+		int lrow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
+		bool ok[UNR];
+#pragma unroll
+		for (int u = 0; u < UNR; u++) {
+			const int ls = (step0 + u) * RSTEP + wave * RPW + g;  // position in sweep order
+			ok[u] = ls < rc;
+			const int lr = ok[u] ? (a.descending ? rc - 1 - ls : ls) : 0;
+			lrow[u] = lr;
+			const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1];
+			dgp[u] = s_dg[lr];
+			jbeg[u] = jend[u] = 0;
+			if (ok[u]) {
+				if (PART == PART_LOWER) {
+					jbeg[u] = rp0;
+					jend[u] = dgp[u];
+				} else if (PART == PART_UPPER) {
+					jbeg[u] = (DSRC == D_VALS_DIAG) ? dgp[u] : dgp[u] + 1;  // first item = diagonal block
+					jend[u] = rp1;
+				} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
+					jbeg[u] = rp0;
+					jend[u] = rp1;
+				}
+			}
+		}
+
+		double2_t bv[UNR][KFIX];
+		double xv[UNR][KFIX];
+		double2_t dv[UNR], r2[UNR], s2[UNR];
+#pragma unroll
+		for (int u = 0; u < UNR; u++) {
+#pragma unroll
+			for (int k = 0; k < KFIX; k++) {
+				const int jj = jbeg[u] + slot + k * NB;
+				bv[u][k].x = 0.0;
+				bv[u][k].y = 0.0;
+				xv[u][k] = 0.0;
+				if (PART != PART_NONE && jj < jend[u]) {
+					bv[u][k] = load_block16<NT>(reinterpret_cast<const double *>(
+					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+					const bool isdiag = (jj == dgp[u]);
+					if (!((PART == PART_UPPER && DSRC == D_VALS_DIAG && isdiag) ||
+					      (PART == PART_OFFDIAG && isdiag))) {
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						xv[u][k] = *reinterpret_cast<const double *>(
+						    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+					}
+				}
+			}
+			dv[u].x = 0.0;
+			dv[u].y = 0.0;
+			if (DSRC == D_DBLOCKS && ok[u] && slot == 0)
+				dv[u] = load_block16<false>(reinterpret_cast<const double *>(
+				    dbase + ((unsigned)lrow[u] * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+			r2[u].x = r2[u].y = 0.0;
+			s2[u].x = s2[u].y = 1.0;
+			if (ok[u] && a.rhs) {
+				r2[u] = *reinterpret_cast<const double2_t *>(
+				    rbase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+				if (a.rscale)
+					s2[u] = *reinterpret_cast<const double2_t *>(
+					    sbase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+			}
+		}
+
+#pragma unroll
+		for (int u = 0; u < UNR; u++) {
+			double d0 = dv[u].x, d1 = dv[u].y;  // entries (2q, 2q+1) of D, in block slot 0
+			double acc0 = 0.0, acc1 = 0.0;
+			if (PART != PART_NONE) {
+#pragma unroll
+				for (int k = 0; k < KFIX; k++) {
+					if (PART == PART_UPPER && DSRC == D_VALS_DIAG && k == 0) {
+						// item 0 of the row is its (inverted) diagonal block: keep it as D
+						const bool isd = (slot == 0);
+						d0 = isd ? bv[u][0].x : d0;
+						d1 = isd ? bv[u][0].y : d1;
+						acc0 += isd ? 0.0 : bv[u][0].x * xv[u][0];
+						acc1 += isd ? 0.0 : bv[u][0].y * xv[u][0];
+					} else {
+						acc0 += bv[u][k].x * xv[u][k];  // xv is zero for skipped / absent items
+						acc1 += bv[u][k].y * xv[u][k];
+					}
+				}
+				for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
+					if (PART == PART_OFFDIAG && jj == dgp[u])
+						continue;
+					const double2_t v2 = load_block16<NT>(reinterpret_cast<const double *>(
+					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+					const int cidx = jj - jlo;
+					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					const double xc = *reinterpret_cast<const double *>(
+					    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+					acc0 += v2.x * xc;
+					acc1 += v2.y * xc;
+				}
+				// over the column bits and the block-slot bit; the row-pair bits h stay
+				acc0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc0);
+				acc1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc1);
+			}
+			const double rv0 = r2[u].x * s2[u].x, rv1 = r2[u].y * s2[u].y;
+
+			double o0, o1;
+			if (POST == POST_SUB) {
+				o0 = rv0 - acc0;
+				o1 = rv1 - acc1;
+			} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
+				const double w0 = (POST == POST_D_SUB) ? rv0 - acc0 : acc0;  // rows 2h, 2h+1 of the vector D multiplies
+				const double w1 = (POST == POST_D_SUB) ? rv1 - acc1 : acc1;
+				// this lane needs component c of that vector: rows 2(c/2), 2(c/2)+1 are held by the lanes
+				// whose row-pair index h equals c/2; every aligned group of HB lanes contains all h
+				double wc;
+				if (BS == 4) {
+					const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
+					const double a10 = dpp_mov<0x55>(w0), a11 = dpp_mov<0x55>(w1);  // quad_perm [1,1,1,1]
+					const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
+					const double s0 = b2 ? a10 : a00, s1 = b2 ? a11 : a01;
+					wc = b1 ? s1 : s0;
+				} else {
+					const int src = (lane & ~(HB - 1)) | (c >> 1);
+					const double t0 = __shfl(w0, src, 64), t1 = __shfl(w1, src, 64);
+					wc = (c & 1) ? t1 : t0;
+				}
+				// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
+				const double p0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
+				const double p1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
+				if (POST == POST_D_SUB) {
+					o0 = p0;
+					o1 = p1;
+				} else {
+					o0 = rv0 - p0;
+					o1 = rv1 - p1;
+				}
+			} else {
+				o0 = a.a * acc0;
+				o1 = a.a * acc1;
+				if (a.b != 0.0) {
+					o0 += a.b * rv0;
+					o1 += a.b * rv1;
+				}
+			}
+
+			if (ok[u] && slot == 0 && q < HB) {
+				double2_t o2;
+				o2.x = o0;
+				o2.y = o1;
+				double2_t *const dst = reinterpret_cast<double2_t *>(
+				    obase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q));
+				if (a.changed) {
+					const double2_t old = *dst;
+					if (!(old.x == o0) || !(old.y == o1))
+						*a.changed = 1;
+				}
+				*dst = o2;
+			}
+		}
+	}
+}
+
+struct Variant {
+	int rchunk = 128, nt = 1, unr = 2, enabled = 1;
+};
+
+static Variant parse_variant(const char *e)
+{
+	Variant v;
+	// BLASTED_HIP_SWEEPW = "generic" | "r<128|256>,nt<0|1>,u<1|2>"   (tuning / A-B measurements)
+	if (!e)
+		return v;
+	if (std::strcmp(e, "generic") == 0) {
+		v.enabled = 0;
+		return v;
+	}
+	int r = 128, nt = 1, unr = 2;
+	if (std::sscanf(e, "r%d,nt%d,u%d", &r, &nt, &unr) == 3) {
+		v.rchunk = r;
+		v.nt = nt;
+		v.unr = unr;
+	}
+	return v;
+}
+
+static Variant &current_variant()
+{
+	static Variant v = parse_variant(std::getenv("BLASTED_HIP_SWEEPW"));
+	return v;
+}
+
+// tuning hook behind blasted_hip_set_tuning(): same syntax as the BLASTED_HIP_SWEEPW variable
+void set_sweepw_variant(const char *spec)
+{
+	current_variant() = parse_variant(spec);
+}
+
+template <int BS, int PART, int POST, int DSRC>
+static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
+{
+#define BHIP_V(RV, NTV, UV)                                                                            \
+	if (v.rchunk == RV && v.nt == NTV && v.unr == UV) {                                                \
+		/* whole-row operators carry 4 straight-line passes, and bs=8 twice the registers per pass:     \
+		   keep them at one step per pass of the loop so that 8 waves per SIMD stay resident */          \
+		constexpr int UEFF = (PART == PART_ALL || PART == PART_OFFDIAG || BS == 8) ? 1 : UV;            \
+		const unsigned grid = (unsigned)(((long)a.pat.nbrows + RV - 1) / RV);                          \
+		hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UEFF>), dim3(grid),    \
+		                   dim3(256), 0, s, a);                                                        \
+		return true;                                                                                   \
+	}
+	BHIP_V(128, 1, 2)
+	BHIP_V(128, 0, 2)
+	BHIP_V(128, 1, 1)
+	BHIP_V(128, 0, 1)
+	BHIP_V(256, 1, 2)
+	BHIP_V(256, 0, 1)
+#undef BHIP_V
+	return false;
+}
+
+template <int BS>
+static bool launch_bs(const SweepArgs &a, Part part, Post post, DSrc dsrc, const Variant &v, hipStream_t s)
+{
+	bool ok = false;
+#define BHIP_CASEW(P, Q, D)                                   \
+	if (part == P && post == Q && dsrc == D)                  \
+		ok = launch_variant<BS, P, Q, D>(a, v, s);
+	BHIP_CASEW(PART_LOWER, POST_SUB, D_NONE)
+	BHIP_CASEW(PART_UPPER, POST_D_SUB, D_VALS_DIAG)
+	BHIP_CASEW(PART_LOWER, POST_D_SUB, D_DBLOCKS)
+	BHIP_CASEW(PART_UPPER, POST_SUB_D, D_DBLOCKS)
+	BHIP_CASEW(PART_OFFDIAG, POST_D_SUB, D_DBLOCKS)
+	BHIP_CASEW(PART_ALL, POST_AXPBY, D_NONE)
+	BHIP_CASEW(PART_NONE, POST_D_SUB, D_DBLOCKS)
+#undef BHIP_CASEW
+	return ok;
+}
+
+// returns false when the tuned kernel does not cover the request (caller uses the generic family)
+bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
+{
+	const Variant &v = current_variant();
+	const int bs = a.pat.bs;
+	if (!v.enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || a.pat.nbrows == 0)
+		return false;
+	// 32-bit byte offsets: the vector and the blocks of one 256-row chunk must stay below 4 GiB
+	const long blkbytes = (long)bs * bs * 8;
+	if ((long)a.pat.nbrows * bs * 8 >= (1L << 32) || 256L * a.pat.max_row_len * blkbytes >= (1L << 32))
+		return false;
+	// 16-byte loads need 16-byte aligned arrays (hipMalloc gives 256; borrowed pointers are checked)
+	auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
+	if (misaligned(a.vals) || misaligned(a.dvals) || misaligned(a.rhs) || misaligned(a.rscale) ||
+	    misaligned(a.xout))
+		return false;
+	const bool ok = (bs == 4) ? launch_bs<4>(a, part, post, dsrc, v, s) : launch_bs<8>(a, part, post, dsrc, v, s);
+	if (ok)
+		BHIP_CHECK(hipGetLastError());
+	return ok;
+}
+
+}  // namespace bhip

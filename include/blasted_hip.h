@@ -145,8 +145,8 @@ int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long
 int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
 
 /* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
- * generic kernel family, or "nb<2|4>,r<128|256>,nt<0|1>,u<1|2>" for the tuned bs=4 kernel; the same
- * strings are read once from the environment variable BLASTED_HIP_SWEEP4.  "factor4=0" / "factor4=1"
+ * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>" for the tuned bs=4/8 kernel; the same strings
+ * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
  * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4). */
 int blasted_hip_set_tuning(const char *spec);
 
