@@ -299,6 +299,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		dev_free(p->upperp);
 		dev_free(p->iluvals);
 		dev_free(p->iluvals2);
+		dev_free(p->finv);
 		dev_free(p->scale);
 		dev_free(p->ytemp);
 		dev_free(p->dblocks);
@@ -490,6 +491,9 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.lowerp = p->lowerp;
 		fa.upperp = p->upperp;
 		fa.changed = nullptr;
+		fa.dinv_scratch = nullptr;
+		if (pat.bs == 8 && !pat.rowmajor)
+			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * 64);
 
 		const long ngroups = (long)pat.nbrows + 8;
 		if (precinfo) {
@@ -960,6 +964,8 @@ int blasted_hip_set_tuning(const char *spec)
 	return guarded([&] {
 		if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
+		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)
+			set_factor8_enabled(spec[8] != '0');
 		else
 			set_sweepw_variant(spec);
 	});

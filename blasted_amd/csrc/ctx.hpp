@@ -78,6 +78,7 @@ struct FactorArgs {
 	const double *in;       // factor values read
 	double *out;            // factor values written (== in for async)
 	int *changed;           // optional flag, as in SweepArgs
+	double *dinv_scratch;   // optional nbrows*bs*bs scratch (bs=8 tuned path: inverted diagonal blocks)
 };
 
 // kernels_sweep.hip
@@ -89,6 +90,9 @@ void set_sweepw_variant(const char *spec);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);
+// kernels_factor8.hip (bs=8 column-major factorisation sweep on the matrix core)
+bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s);
+void set_factor8_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,
@@ -135,6 +139,7 @@ struct blasted_hip_prec_s {
 	long npairs = -1;
 
 	double *iluvals = nullptr, *iluvals2 = nullptr;
+	double *finv = nullptr;  // inverted diagonal blocks of the current iterate (bs=8 factorisation sweeps)
 	double *scale = nullptr;
 	bool factored = false, scaled = false;
 	double *ytemp = nullptr;

@@ -390,6 +390,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 		return;
 	if (launch_factor4(a, s))
 		return;
+	if (launch_factor8(a, a.dinv_scratch, s))
+		return;
 	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
 		hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, false>), dim3(grid), dim3(256), 0, s, a,

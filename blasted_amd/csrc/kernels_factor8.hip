@@ -1,0 +1,186 @@
+// kernels_factor8.hip -- asynchronous block-ILU(0) factorisation sweep for bs = 8, column-major blocks
+// (async_block_ilu0_factorize, src/kernels/kernels_ilu0_factorize.hpp:71-98), BASELINE.json's config 5:
+// "block-ILU with MFMA for the 8x8 block GEMMs".  At bs = 8 the block product is a dense 8x8x8
+// contraction and goes to the matrix core.
+//
+// One wave owns one 8x8 block at a time: its 64 lanes are the 64 entries of the result, arranged as the
+// four 4x4 output tiles (ti,tj) of v_mfma_f64_4x4x4_4b_f64 (block slot b = 2 ti + tj; operand layout
+// probed on gfx950, see kernels_factor4.hip):
+//     lane 16k + 4b + m   holds   D(4ti + k, 4tj + m),
+//     A-operand for inner tile tk:  X(4ti + m, 4tk + k),     B-operand:  Y(4tk + k, 4tj + m).
+// An 8x8x8 product is two MFMA instructions (tk = 0, 1) accumulating into the same four tiles, and every
+// operand is loaded from its 512-byte block directly in operand layout (per-lane element offsets): the
+// sum  S = A - sum L U  needs no lane exchange at all.  For a lower block, S is re-read in A-operand
+// layout with two shuffles and multiplied by inverse(U_jj) on the matrix core too.
+//
+// inverse(U_jj): the reference inverts U_jj inside the row kernel, once per lower block and sweep
+// (kernels_ilu0_factorize.hpp:91).  Here the diagonal blocks of the sweep's input iterate are inverted
+// once per sweep by a pre-pass (invert_blocks_kernel, Gauss-Jordan with partial pivoting) into a side
+// array that the lower blocks read in B-operand layout.  For synchronous (Jacobi) sweeps this is the
+// same arithmetic on the same iterate; for in-place asynchronous sweeps the inverse may be one update
+// older than the freshest diagonal, which chaotic iteration permits.
+//
+// All control flow is wave-uniform (a wave walks one block-row); indices of a 32-row chunk are staged in
+// LDS; each entry of the factor is produced in registers and stored once.
+#include "ctx.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace bhip {
+
+namespace {
+
+constexpr int F8_RCHUNK = 32;
+constexpr int F8_CAPB = 16 * F8_RCHUNK;
+constexpr int F8_CAPP = 16 * F8_RCHUNK;
+
+__device__ __forceinline__ unsigned xcd_chunk_f8(unsigned bid, unsigned nwg)
+{
+	const unsigned xcd = bid & 7u, local = bid >> 3;
+	const unsigned base = nwg >> 3, rem = nwg & 7u;
+	return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+
+__device__ __forceinline__ double mfma444(const double a, const double b, const double c)
+{
+	return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const double *dinv)
+{
+	__shared__ int s_rp[F8_RCHUNK + 1];
+	__shared__ int s_col[F8_CAPB];
+	__shared__ int s_pp[F8_CAPB + 1];
+	__shared__ int s_lp[F8_CAPP];
+	__shared__ int s_up[F8_CAPP];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int k = lane >> 4, b = (lane >> 2) & 3, m = lane & 3;
+	const int ti = b >> 1, tj = b & 1;
+	// element offsets inside a column-major 8x8 block (offset = c*8 + r)
+	const int offD = (4 * tj + m) * 8 + 4 * ti + k;   // (r = 4ti+k, c = 4tj+m)
+	const int offA0 = (0 + k) * 8 + 4 * ti + m;        // (r = 4ti+m, c = k)      tk = 0
+	const int offA1 = (4 + k) * 8 + 4 * ti + m;        // (r = 4ti+m, c = 4+k)    tk = 1
+	const int offB0 = (4 * tj + m) * 8 + 0 + k;        // (r = k,     c = 4tj+m)  tk = 0
+	const int offB1 = (4 * tj + m) * 8 + 4 + k;        // (r = 4+k,   c = 4tj+m)  tk = 1
+	const int srcA0 = 16 * m + 4 * (2 * ti + 0) + k;   // lane holding S(4ti+m, k)   in D layout
+	const int srcA1 = 16 * m + 4 * (2 * ti + 1) + k;   // lane holding S(4ti+m, 4+k)
+
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_chunk_f8(blockIdx.x, gridDim.x);
+	const int r0 = (int)chunk * F8_RCHUNK;
+	const int rc = (nb - r0) < F8_RCHUNK ? (nb - r0) : F8_RCHUNK;
+
+	for (int q = tid; q <= rc; q += 256)
+		s_rp[q] = a.pat.browptr[r0 + q];
+	__syncthreads();
+	const int jlo = __builtin_amdgcn_readfirstlane(s_rp[0]);
+	const int jhi = __builtin_amdgcn_readfirstlane(s_rp[rc]);
+	const int nblk = (jhi - jlo) < F8_CAPB ? (jhi - jlo) : F8_CAPB;
+	for (int q = tid; q < nblk; q += 256)
+		s_col[q] = a.pat.bcolind[jlo + q];
+	for (int q = tid; q <= nblk; q += 256)
+		s_pp[q] = a.posptr[jlo + q];
+	__syncthreads();
+	const int plo = __builtin_amdgcn_readfirstlane(s_pp[0]);
+	const int phi = __builtin_amdgcn_readfirstlane(s_pp[nblk]);
+	const int npair = (phi - plo) < F8_CAPP ? (phi - plo) : F8_CAPP;
+	for (int q = tid; q < npair; q += 256) {
+		s_lp[q] = a.lowerp[plo + q];
+		s_up[q] = a.upperp[plo + q];
+	}
+	__syncthreads();
+
+	for (int ls = wave; ls < rc; ls += 4) {
+		const int irow = r0 + ls;
+		const int jbeg = __builtin_amdgcn_readfirstlane(s_rp[ls]);
+		const int jend = __builtin_amdgcn_readfirstlane(s_rp[ls + 1]);
+		for (int jpos = jbeg; jpos < jend; jpos++) {
+			const int bidx = jpos - jlo;
+			int col, kb, ke;
+			if (bidx < F8_CAPB) {
+				col = s_col[bidx];
+				kb = s_pp[bidx];
+				ke = s_pp[bidx + 1];
+			} else {
+				col = a.pat.bcolind[jpos];
+				kb = a.posptr[jpos];
+				ke = a.posptr[jpos + 1];
+			}
+			col = __builtin_amdgcn_readfirstlane(col);
+			kb = __builtin_amdgcn_readfirstlane(kb);
+			ke = __builtin_amdgcn_readfirstlane(ke);
+			const bool lower = irow > col;
+
+			double sval = a.avals[(long)jpos * 64 + offD];
+			double d0 = 0.0, d1 = 0.0;
+			if (lower) {
+				d0 = dinv[(long)col * 64 + offB0];
+				d1 = dinv[(long)col * 64 + offB1];
+			}
+			if (a.scale)
+				sval *= a.scale[(long)irow * 8 + 4 * ti + k] * a.scale[(long)col * 8 + 4 * tj + m];
+
+			double acc = 0.0;
+			for (int kk = kb; kk < ke; kk++) {
+				const int pidx = kk - plo;
+				int lp, up;
+				if (pidx < F8_CAPP) {
+					lp = s_lp[pidx];
+					up = s_up[pidx];
+				} else {
+					lp = a.lowerp[kk];
+					up = a.upperp[kk];
+				}
+				const double *const lblk = a.in + (long)lp * 64, *const ublk = a.in + (long)up * 64;
+				const double l0 = lblk[offA0], l1 = lblk[offA1];
+				const double u0 = ublk[offB0], u1 = ublk[offB1];
+				acc = mfma444(l0, u0, acc);
+				acc = mfma444(l1, u1, acc);
+			}
+			double res = sval - acc;
+
+			if (lower) {
+				const double sa0 = __shfl(res, srcA0, 64), sa1 = __shfl(res, srcA1, 64);
+				double prod = mfma444(sa0, d0, 0.0);
+				prod = mfma444(sa1, d1, prod);
+				res = prod;
+			}
+
+			double *const dst = a.out + (long)jpos * 64 + offD;
+			if (a.changed && !(*dst == res))
+				*a.changed = 1;
+			*dst = res;
+		}
+	}
+}
+
+int g_factor8_enabled = -1;
+
+}  // namespace
+
+void set_factor8_enabled(int on)
+{
+	g_factor8_enabled = on;
+}
+
+// returns false when the tuned kernel does not cover the request (caller uses the generic kernel).
+// dinv_scratch: nbrows*64 doubles, receives the inverted diagonal blocks of a.in.
+bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s)
+{
+	if (g_factor8_enabled < 0) {
+		const char *e = std::getenv("BLASTED_HIP_FACTOR8");
+		g_factor8_enabled = (e && std::strcmp(e, "0") == 0) ? 0 : 1;
+	}
+	if (!g_factor8_enabled || !dinv_scratch || a.pat.bs != 8 || a.pat.rowmajor || a.pat.nbrows == 0)
+		return false;
+	launch_invert_diag_blocks(a.pat, a.in, 1, dinv_scratch, 0, s);
+	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F8_RCHUNK - 1) / F8_RCHUNK);
+	hipLaunchKernelGGL(factor8_kernel, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+	BHIP_CHECK(hipGetLastError());
+	return true;
+}
+
+}  // namespace bhip
