@@ -233,6 +233,120 @@ __global__ __launch_bounds__(256) void invert_blocks_kernel(const Pattern pat, c
 		dst[dblk * BS2 + e] = inv;
 }
 
+// Same operation for bs >= 5 (Gauss-Jordan with partial pivoting, as Eigen's PartialPivLU-based
+// inverse() does above n = 4), organised the other way round: ONE THREAD inverts one block entirely in
+// registers -- no cross-lane traffic at all -- and the 64 blocks of a wave travel between HBM and the
+// threads through an LDS transpose, so that global loads and stores stay coalesced (a wave instruction
+// moves one whole block).  All register-array indices are compile-time constants (row swaps and the
+// final column un-permutation are conditional moves).
+template <int BS, bool RM>
+__global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat, const double *src,
+                                                               const int src_by_diag, double *dst,
+                                                               const int dst_by_diag)
+{
+	constexpr int BS2 = BS * BS, LD = BS2 + 1;  // +1: conflict-free strided LDS reads
+	__shared__ double tile[64 * LD];
+	const int t = threadIdx.x;
+	const long row0 = (long)blockIdx.x * 64;
+	const long myrow = row0 + t;
+	const bool rowok = myrow < pat.nbrows;
+	const long dgpos = rowok ? pat.diagind[myrow] : 0;
+	const long sblk = src_by_diag ? dgpos : myrow, dblk = dst_by_diag ? dgpos : myrow;
+	const int nrows = (pat.nbrows - row0) < 64 ? (int)(pat.nbrows - row0) : 64;
+
+	// HBM -> LDS, one block per wave instruction
+	for (int i = 0; i < nrows; i++) {
+		const long blk = __shfl(sblk, i, 64);
+		if (t < BS2)
+			tile[i * LD + t] = src[blk * BS2 + t];
+	}
+	__syncthreads();
+
+	double m[BS][BS];
+	if (rowok) {
+#pragma unroll
+		for (int r = 0; r < BS; r++)
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[r][c] = tile[t * LD + (RM ? r * BS + c : c * BS + r)];
+	} else {
+#pragma unroll
+		for (int r = 0; r < BS; r++)
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[r][c] = (r == c) ? 1.0 : 0.0;
+	}
+
+	// in-place Gauss-Jordan with partial pivoting; piv[p] = row swapped with p at step p
+	int piv[BS];
+#pragma unroll
+	for (int p = 0; p < BS; p++) {
+		int pr = p;
+		double best = fabs(m[p][p]);
+#pragma unroll
+		for (int r = p + 1; r < BS; r++) {
+			const double v = fabs(m[r][p]);
+			if (v > best) {
+				best = v;
+				pr = r;
+			}
+		}
+		piv[p] = pr;
+#pragma unroll
+		for (int r = p + 1; r < BS; r++) {
+			const bool sw = (pr == r);
+#pragma unroll
+			for (int c = 0; c < BS; c++) {
+				const double a = m[p][c], b = m[r][c];
+				m[p][c] = sw ? b : a;
+				m[r][c] = sw ? a : b;
+			}
+		}
+		const double pinv = 1.0 / m[p][p];
+		m[p][p] = 1.0;
+#pragma unroll
+		for (int c = 0; c < BS; c++)
+			m[p][c] *= pinv;
+#pragma unroll
+		for (int r = 0; r < BS; r++) {
+			if (r == p)
+				continue;
+			const double f = m[r][p];
+			m[r][p] = 0.0;
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[r][c] -= f * m[p][c];
+		}
+	}
+	// undo the row swaps as column swaps, last first
+#pragma unroll
+	for (int p = BS - 1; p >= 0; p--) {
+#pragma unroll
+		for (int q = p + 1; q < BS; q++) {
+			const bool sw = (piv[p] == q);
+#pragma unroll
+			for (int r = 0; r < BS; r++) {
+				const double a = m[r][p], b = m[r][q];
+				m[r][p] = sw ? b : a;
+				m[r][q] = sw ? a : b;
+			}
+		}
+	}
+
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < BS; r++)
+#pragma unroll
+		for (int c = 0; c < BS; c++)
+			tile[t * LD + (RM ? r * BS + c : c * BS + r)] = m[r][c];
+	__syncthreads();
+	for (int i = 0; i < nrows; i++) {
+		const long blk = __shfl(dblk, i, 64);
+		if (t < BS2)
+			dst[blk * BS2 + t] = tile[i * LD + t];
+	}
+}
+
 // INIT_F_ORIGINAL with scaling / INIT_F_SGS first pass: ilu = scaled A
 template <int BS, bool RM>
 __global__ void scaled_copy_kernel(const Pattern pat, const double *avals, const double *scale,
@@ -426,9 +540,15 @@ void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_b
 	if (pat.nbrows == 0)
 		return;
 	BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
-		const unsigned grid = (unsigned)(((long)pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
-		hipLaunchKernelGGL((invert_blocks_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat, src,
-		                   (int)src_by_diag, dst, (int)dst_by_diag);
+		if (BS >= 5) {
+			const unsigned grid = (unsigned)(((long)pat.nbrows + 63) / 64);
+			hipLaunchKernelGGL((invert_blocks_tpb_kernel<(BS >= 5 ? BS : 5), RM>), dim3(grid), dim3(64), 0, s,
+			                   pat, src, (int)src_by_diag, dst, (int)dst_by_diag);
+		} else {
+			const unsigned grid = (unsigned)(((long)pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+			hipLaunchKernelGGL((invert_blocks_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat, src,
+			                   (int)src_by_diag, dst, (int)dst_by_diag);
+		}
 	})
 	BHIP_CHECK(hipGetLastError());
 }
