@@ -375,6 +375,14 @@ int blasted_hip_set_pattern(blasted_hip_prec p, int nbrows, int nnzb, int bs, in
 			p->browptr_own = p->bcolind_own = p->diagind_own = nullptr;
 			BHIP_FAIL(BLASTED_HIP_EINVAL, msg);
 		}
+		if (!sweep_offsets_fit(pat)) {
+			dev_free(p->browptr_own);
+			dev_free(p->bcolind_own);
+			dev_free(p->diagind_own);
+			p->browptr_own = p->bcolind_own = p->diagind_own = nullptr;
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "set_pattern: matrix exceeds this build's 32-bit in-chunk offsets "
+			                              "(vector must be < 4 GiB, 256 * longest row * block bytes < 4 GiB)");
+		}
 		p->pat = pat;
 		p->have_pattern = true;
 	});

@@ -11,14 +11,19 @@
 //   BLAS_BSR::matrix_apply/gemv3  blas/matvecs.cpp:26-75            ALL       AXPBY    -
 //   BJacobi apply                 solverops_jacobi.cpp:51-63        NONE      D_SUB    dblocks
 //
+// This file is the general family: every instantiated block size (1, 2, 3, 4, 5, 7, 8) in both block
+// layouts; column-major bs = 4 and 8 are normally taken by the wide kernel of kernels_sweepw.hip.
+//
 // Mapping (wave64): a group of G lanes owns one block-row; inside the group SUB = BSP*BSP lanes
-// (BSP = bs rounded up to a power of two) own one stored block, lane (r,c) holding entry (r,c), so a
-// block is read by one coalesced load and NB = G/SUB blocks of the row are in flight per iteration.
-// The bs x bs mat-vec is one FMA per lane followed by an xor-butterfly over the column bits (and the
-// block-slot bits); D is applied with a second butterfly.  Groups of one wave own consecutive rows,
-// so rhs loads and the result store of a wave are contiguous.  Workgroups are renumbered so that each
-// XCD sweeps one contiguous range of rows (its L2 then serves the neighbour gathers, and inside an
-// XCD later workgroups see earlier ones' updates: Gauss-Seidel-like inside, Jacobi-like across).
+// (BSP = bs rounded up to a power of two) own one stored block, lane (r,c) = (u % BSP, u / BSP) holding
+// entry (r,c), so a block is one coalesced load and NB = G/SUB blocks of the row ride in one load
+// instruction (scalar CSR: 4 entries).  A workgroup owns RCHUNK consecutive rows of the sweep and stages
+// their browptr / diagind / bcolind range in LDS once, coalesced, so that no value load waits on an
+// index load from HBM; all loads of a row step (KFIX predicated block passes, straight-line) are issued
+// before the first use, rows with more blocks finish in a remainder loop.  The bs x bs mat-vec is one
+// FMA per lane plus an all-reduce over the column bits and the block-slot bits on the VALU (lanes.hpp);
+// D is applied with one broadcast and a second all-reduce.  Workgroups are renumbered so that each XCD
+// sweeps one contiguous range of rows.
 //
 // Async semantics: with xin == xout the sweep is chaotic relaxation -- iterate values written by other
 // waves of the same launch may or may not be observed (plain loads; stale L1/L2 lines are older
@@ -26,127 +31,192 @@
 // produced in registers and stored once: no partial sum is ever published
 // (kernels_ilu0_factorize.hpp:34-40).
 #include "ctx.hpp"
+#include "lanes.hpp"
 
 namespace bhip {
 
 template <int BS>
 struct Geo {
 	static constexpr int BSP = BS <= 1 ? 1 : (BS <= 2 ? 2 : (BS <= 4 ? 4 : 8));
-	static constexpr int SUB = BSP * BSP;
-	// lanes per block-row
-	static constexpr int G = BS == 1 ? 4 : (BS == 2 ? 8 : SUB);
-	static constexpr int NB = G / SUB;
-	static constexpr int RPW = 64 / G;        // rows per wave
-	static constexpr int RPB = 4 * RPW;       // rows per 256-thread workgroup
+	static constexpr int SUB = BSP * BSP;                         // lanes per block
+	static constexpr int G = BS == 1 ? 4 : (BS <= 4 ? 16 : 64);  // lanes per block-row
+	static constexpr int NB = G / SUB;                            // block slots per row
+	static constexpr int RPW = 64 / G;                            // rows per wave and step
+	static constexpr int RSTEP = 4 * RPW;                         // rows per workgroup and step
+	static constexpr int RCHUNK = BS <= 4 ? 128 : 64;             // rows per workgroup
+	static constexpr int CAP = (BS == 1 ? 32 : 16) * RCHUNK;      // staged column indices
+	static constexpr int LOBIT = BSP == 1 ? 0 : (BSP == 2 ? 1 : (BSP == 4 ? 2 : 3));
+	static constexpr int HIBIT = G == 4 ? 2 : (G == 16 ? 4 : 6);
 };
-
-// Contiguous range of workgroup ids per XCD (workgroups are dealt round-robin to the 8 XCDs).
-__device__ __forceinline__ unsigned xcd_chunk(unsigned bid, unsigned nwg)
-{
-	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
-}
-
-template <int OFF_LO, int OFF_HI>
-__device__ __forceinline__ double butterfly(double v)
-{
-#pragma unroll
-	for (int off = OFF_LO; off < OFF_HI; off <<= 1)
-		v += __shfl_xor(v, off, 64);
-	return v;
-}
 
 template <int BS, bool RM, int PART, int POST, int DSRC>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
 	using Ge = Geo<BS>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
+	constexpr int RPW = Ge::RPW, RSTEP = Ge::RSTEP, RCHUNK = Ge::RCHUNK, CAP = Ge::CAP;
+	// straight-line passes: enough for a 7-point row's lower part or diagonal + upper part, twice as
+	// many for operators that visit the whole row
+	constexpr int KFIX = (NB >= 4 ? 1 : 4) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__shared__ int s_rp[RCHUNK + 1];
+	__shared__ int s_dg[RCHUNK];
+	__shared__ int s_col[CAP];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
 	const int g = lane / G, t = lane % G;
-	const int sub = t / SUB, u = t % SUB;
+	const int slot = t / SUB, u = t % SUB;
 	const int r = u % BSP, c = u / BSP;
 	const bool active = (r < BS) && (c < BS);
 	const int e = RM ? r * BS + c : c * BS + r;
-
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
-	const long rowlin = (long)chunk * Ge::RPB + wave * Ge::RPW + g;
-	const bool rowok = rowlin < a.pat.nbrows;
-	const int i = rowok ? (a.descending ? a.pat.nbrows - 1 - (int)rowlin : (int)rowlin) : 0;
-
-	int jbeg = 0, jend = 0, dg = 0;
-	if (rowok) {
-		dg = a.pat.diagind[i];
-		if (PART == PART_LOWER) {
-			jbeg = a.pat.browptr[i];
-			jend = dg;
-		} else if (PART == PART_UPPER) {
-			jbeg = dg + 1;
-			jend = a.pat.browptr[i + 1];
-		} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
-			jbeg = a.pat.browptr[i];
-			jend = a.pat.browptr[i + 1];
-		}
-	}
-
-	// D entry and rhs are independent of the gather loop: issue their loads first
-	double d = 0.0;
-	if (DSRC != D_NONE && rowok && active) {
-		if (DSRC == D_VALS_DIAG)
-			d = a.dvals[(long)dg * BS2 + e];
-		else if (DSRC == D_DBLOCKS)
-			d = a.dvals[(long)i * BS2 + e];
-		else
-			d = 1.0 / a.dvals[dg];
-	}
-	double rv = 0.0;
-	if (rowok && r < BS && a.rhs) {
-		rv = a.rhs[(long)i * BS + r];
-		if (a.rscale)
-			rv *= a.rscale[(long)i * BS + r];
-	}
-
-	double acc = 0.0;
-	if (PART != PART_NONE) {
-		for (int jj = jbeg + sub; jj < jend; jj += NB) {
-			if (PART == PART_OFFDIAG && jj == dg)
-				continue;
-			const int col = a.pat.bcolind[jj];
-			if (active)
-				acc += a.vals[(long)jj * BS2 + e] * a.xin[(long)col * BS + c];
-		}
-		acc = butterfly<BSP, G>(acc);  // over the column bits and the block-slot bits
-	}
-
 	const int gbase = lane & ~(G - 1);
-	double out;
-	if (POST == POST_SUB) {
-		out = rv - acc;
-	} else if (POST == POST_D_SUB) {
-		const double v = rv - acc;                    // lanes (r,*) hold v[r]
-		const double vc = __shfl(v, gbase + c, 64);   // lane (c,0) of block slot 0 holds v[c]
-		out = butterfly<BSP, SUB>(active ? d * vc : 0.0);
-	} else if (POST == POST_SUB_D) {
-		const double wc = __shfl(acc, gbase + c, 64);
-		out = rv - butterfly<BSP, SUB>(active ? d * wc : 0.0);
-	} else {
-		out = a.a * acc;
-		if (a.b != 0.0)
-			out += a.b * rv;
-	}
 
-	if (rowok && sub == 0 && c == 0 && r < BS) {
-		if (a.changed && !(a.xout[(long)i * BS + r] == out))
-			*a.changed = 1;
-		a.xout[(long)i * BS + r] = out;
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const long lin0 = (long)chunk * RCHUNK;
+	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
+	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;  // rows [r0, r0 + rc)
+
+	for (int k = tid; k <= rc; k += 256)
+		s_rp[k] = a.pat.browptr[r0 + k];
+	for (int k = tid; k < rc; k += 256)
+		s_dg[k] = a.pat.diagind[r0 + k];
+	__syncthreads();
+	int jlo, jhi;
+	if (PART == PART_LOWER) {
+		jlo = s_rp[0];
+		jhi = s_dg[rc - 1];
+	} else if (PART == PART_UPPER) {
+		jlo = s_dg[0];
+		jhi = s_rp[rc];
+	} else {
+		jlo = s_rp[0];
+		jhi = s_rp[rc];
+	}
+	jlo = __builtin_amdgcn_readfirstlane(jlo);
+	jhi = __builtin_amdgcn_readfirstlane(jhi);
+	if (PART != PART_NONE) {
+		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
+		for (int k = tid; k < ncol; k += 256)
+			s_col[k] = a.pat.bcolind[jlo + k];
+	}
+	__syncthreads();
+
+	// wave-uniform 64-bit bases + 32-bit per-lane byte offsets (limits checked by sweep_offsets_fit)
+	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * BS2);
+	const char *const xbase = reinterpret_cast<const char *>(a.xin);
+	const char *const rbase = reinterpret_cast<const char *>(a.rhs + (long)r0 * BS);
+	const char *const sbase = reinterpret_cast<const char *>(a.rscale + (long)r0 * BS);
+	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * BS2);
+	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * BS);
+
+	for (int step = 0; step < RCHUNK / RSTEP; step++) {
+		const int ls = step * RSTEP + wave * RPW + g;  // position in sweep order
+		const bool ok = ls < rc;
+		const int lr = ok ? (a.descending ? rc - 1 - ls : ls) : 0;
+		const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1], dg = s_dg[lr];
+		int jbeg = 0, jend = 0;
+		if (ok) {
+			if (PART == PART_LOWER) {
+				jbeg = rp0;
+				jend = dg;
+			} else if (PART == PART_UPPER) {
+				// the diagonal item rides in front of the upper ones when D is the factor's own diagonal
+				jbeg = (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) ? dg : dg + 1;
+				jend = rp1;
+			} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
+				jbeg = rp0;
+				jend = rp1;
+			}
+		}
+
+		double bv[KFIX], xv[KFIX];
+#pragma unroll
+		for (int k = 0; k < KFIX; k++) {
+			const int jj = jbeg + slot + k * NB;
+			bv[k] = 0.0;
+			xv[k] = 0.0;
+			if (PART != PART_NONE && jj < jend && active) {
+				bv[k] = *reinterpret_cast<const double *>(
+				    vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+				const bool isdiag = (jj == dg);
+				if (!((PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && isdiag) ||
+				      (PART == PART_OFFDIAG && isdiag))) {
+					const int cidx = jj - jlo;
+					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					xv[k] = *reinterpret_cast<const double *>(
+					    xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+				}
+			}
+		}
+		double d = 0.0;
+		if (DSRC == D_DBLOCKS && ok && active && slot == 0)
+			d = *reinterpret_cast<const double *>(dbase + ((unsigned)lr * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+		double rv = 0.0;
+		if (ok && r < BS && a.rhs) {
+			rv = *reinterpret_cast<const double *>(rbase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
+			if (a.rscale)
+				rv *= *reinterpret_cast<const double *>(sbase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
+		}
+
+		double acc = 0.0;
+		if (PART != PART_NONE) {
+#pragma unroll
+			for (int k = 0; k < KFIX; k++) {
+				if (PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && k == 0) {
+					const bool isd = (slot == 0);  // item 0 of the row: its diagonal block / entry
+					if (DSRC == D_VALS_DIAG)
+						d = isd ? bv[0] : d;
+					else
+						d = (isd && ok) ? 1.0 / bv[0] : d;
+					acc += isd ? 0.0 : bv[0] * xv[0];
+				} else
+					acc += bv[k] * xv[k];  // xv is zero for skipped / absent items
+			}
+			for (int jj = jbeg + slot + KFIX * NB; jj < jend; jj += NB) {
+				if (PART == PART_OFFDIAG && jj == dg)
+					continue;
+				if (active) {
+					const int cidx = jj - jlo;
+					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					acc += *reinterpret_cast<const double *>(
+					           vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e)) *
+					       *reinterpret_cast<const double *>(
+					           xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+				}
+			}
+			acc = allreduce_bits<Ge::LOBIT, Ge::HIBIT>(acc);  // lanes (r,*,*) now hold row r of the sum
+		}
+
+		double out;
+		if (POST == POST_SUB) {
+			out = rv - acc;
+		} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
+			const double w = (POST == POST_D_SUB) ? rv - acc : acc;
+			const double wc = __shfl(w, gbase + c, 64);  // lane (c,0) of block slot 0 holds component c
+			// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
+			const double p = allreduce_bits<Ge::LOBIT, Ge::HIBIT>((active && slot == 0) ? d * wc : 0.0);
+			out = (POST == POST_D_SUB) ? p : rv - p;
+		} else {
+			out = a.a * acc;
+			if (a.b != 0.0)
+				out += a.b * rv;
+		}
+
+		if (ok && slot == 0 && c == 0 && r < BS) {
+			double *const dst = reinterpret_cast<double *>(obase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
+			if (a.changed && !(*dst == out))
+				*a.changed = 1;
+			*dst = out;
+		}
 	}
 }
 
 template <int BS, bool RM>
 static void dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
-	const unsigned grid = (unsigned)(((long)a.pat.nbrows + Geo<BS>::RPB - 1) / Geo<BS>::RPB);
+	const unsigned grid = (unsigned)(((long)a.pat.nbrows + Geo<BS>::RCHUNK - 1) / Geo<BS>::RCHUNK);
 	if (grid == 0)
 		return;
 #define BHIP_CASE(P, Q, D)                                                                       \
@@ -178,6 +248,14 @@ static void dispatch_layout(const SweepArgs &a, Part part, Post post, DSrc dsrc,
 bool sweep_supported(int bs)
 {
 	return bs >= 1 && bs <= 8 && bs != 6;
+}
+
+// 32-bit byte offsets inside a chunk: the vector and the blocks of one 256-row chunk must stay below
+// 4 GiB.  Checked once per pattern in set_pattern (capi.hip).
+bool sweep_offsets_fit(const Pattern &pat)
+{
+	const long blkbytes = (long)pat.bs * pat.bs * 8;
+	return (long)pat.nbrows * pat.bs * 8 < (1L << 32) && 256L * pat.max_row_len * blkbytes < (1L << 32);
 }
 
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)

@@ -21,6 +21,7 @@
 //  * wave-uniform 64-bit bases + 32-bit per-lane byte offsets (halves address registers/arithmetic);
 //  * XCD-aware chunk numbering: each XCD sweeps one contiguous range of rows.
 #include "ctx.hpp"
+#include "lanes.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -29,67 +30,12 @@ namespace bhip {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned xcd_chunkw(unsigned bid, unsigned nwg)
-{
-	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
-}
-
 template <bool NT>
 __device__ __forceinline__ double2_t load_block16(const double *p)
 {
 	if (NT)
 		return __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p));
 	return *reinterpret_cast<const double2_t *>(p);
-}
-
-// ---- cross-lane sums on the VALU
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(const double v)
-{
-	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-	return __hiloint2double(hi, lo);
-}
-
-// sum of the value with its partner 16 lanes away (lane ^ 16), in every lane
-__device__ __forceinline__ double xor16_sum(const double v)
-{
-	typedef unsigned v2u __attribute__((ext_vector_type(2)));
-	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-	const v2u a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-	const v2u b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
-}
-
-// ... 32 lanes away (lane ^ 32)
-__device__ __forceinline__ double xor32_sum(const double v)
-{
-	typedef unsigned v2u __attribute__((ext_vector_type(2)));
-	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-	const v2u a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-	const v2u b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
-}
-
-// All-reduce over lane bits [LOBIT, HIBIT) (HIBIT <= 6), every other bit kept.  Inside a 16-lane DPP row
-// the rotations row_ror 8, 4, 2 applied in this order sum bits 3, 2, 1: after each step the value is
-// periodic in the bit just summed, so the wrap-around of the next rotation lands on an equal value.
-template <int LOBIT, int HIBIT>
-__device__ __forceinline__ double allreduce_bits(double v)
-{
-	if (LOBIT <= 3 && HIBIT > 3)
-		v += dpp_mov<0x128>(v);  // row_ror:8
-	if (LOBIT <= 2 && HIBIT > 2)
-		v += dpp_mov<0x124>(v);  // row_ror:4
-	if (LOBIT <= 1 && HIBIT > 1)
-		v += dpp_mov<0x122>(v);  // row_ror:2
-	if (LOBIT <= 4 && HIBIT > 4)
-		v = xor16_sum(v);
-	if (LOBIT <= 5 && HIBIT > 5)
-		v = xor32_sum(v);
-	return v;
 }
 
 template <int BS>
@@ -126,7 +72,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	const int c = q / HB, h = q % HB;  // column of this lane's two entries, row pair (2h, 2h+1)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunkw(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
 	// rows of this chunk in index order: [r0, r0 + rc)
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
@@ -413,10 +359,6 @@ bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStrea
 	const Variant &v = current_variant();
 	const int bs = a.pat.bs;
 	if (!v.enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || a.pat.nbrows == 0)
-		return false;
-	// 32-bit byte offsets: the vector and the blocks of one 256-row chunk must stay below 4 GiB
-	const long blkbytes = (long)bs * bs * 8;
-	if ((long)a.pat.nbrows * bs * 8 >= (1L << 32) || 256L * a.pat.max_row_len * blkbytes >= (1L << 32))
 		return false;
 	// 16-byte loads need 16-byte aligned arrays (hipMalloc gives 256; borrowed pointers are checked)
 	auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };

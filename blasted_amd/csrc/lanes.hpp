@@ -1,0 +1,74 @@
+// lanes.hpp -- wave64 cross-lane helpers shared by the sweep kernels (device code only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace bhip {
+
+// Contiguous range of workgroup ids per XCD (workgroups are dealt round-robin to the 8 XCDs): each XCD
+// then sweeps one contiguous range of block-rows, so its L2 serves the neighbour gathers and later
+// workgroups of the XCD observe earlier ones' updates.
+__device__ __forceinline__ unsigned xcd_contiguous_chunk(unsigned bid, unsigned nwg)
+{
+	const unsigned xcd = bid & 7u, local = bid >> 3;
+	const unsigned base = nwg >> 3, rem = nwg & 7u;
+	return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(const double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+// v[lane] + v[lane ^ 16] in every lane (v_permlane16_swap)
+__device__ __forceinline__ double xor16_sum(const double v)
+{
+	typedef unsigned v2u __attribute__((ext_vector_type(2)));
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const v2u a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+	const v2u b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
+// v[lane] + v[lane ^ 32] in every lane (v_permlane32_swap)
+__device__ __forceinline__ double xor32_sum(const double v)
+{
+	typedef unsigned v2u __attribute__((ext_vector_type(2)));
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const v2u a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+	const v2u b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
+// All-reduce (sum) over lane bits [LOBIT, HIBIT), every other bit kept; all on the VALU.
+//  * bits 0 and 1: exact xor exchanges inside a quad (quad_perm);
+//  * bits 2 and 3 (and bit 1 when the range reaches bit 3): row rotations.  Inside a 16-lane DPP row,
+//    row_ror 8, 4, 2 applied in this order sum bits 3, 2, 1: after each step the value is periodic in the
+//    bit just summed, so the wrap-around of the next rotation lands on an equal value.  This needs the
+//    range to include bit 3 whenever it includes bit 2 (static_assert below);
+//  * bits 4 and 5: v_permlane16_swap / v_permlane32_swap.
+template <int LOBIT, int HIBIT>
+__device__ __forceinline__ double allreduce_bits(double v)
+{
+	static_assert(HIBIT <= 6 && LOBIT >= 0 && LOBIT <= HIBIT, "lane bits");
+	static_assert(!(LOBIT <= 2 && HIBIT > 2) || HIBIT > 3, "a range containing bit 2 must contain bit 3");
+	constexpr bool rot = HIBIT > 3;  // rotations usable for bits 1..3
+	if (LOBIT <= 3 && HIBIT > 3)
+		v += dpp_mov<0x128>(v);  // row_ror:8
+	if (LOBIT <= 2 && HIBIT > 2)
+		v += dpp_mov<0x124>(v);  // row_ror:4
+	if (LOBIT <= 1 && HIBIT > 1)
+		v += rot ? dpp_mov<0x122>(v) : dpp_mov<0x4E>(v);  // row_ror:2 | quad_perm [2,3,0,1]
+	if (LOBIT <= 0 && HIBIT > 0)
+		v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+	if (LOBIT <= 4 && HIBIT > 4)
+		v = xor16_sum(v);
+	if (LOBIT <= 5 && HIBIT > 5)
+		v = xor32_sum(v);
+	return v;
+}
+
+}  // namespace bhip
