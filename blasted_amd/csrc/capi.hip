@@ -500,8 +500,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.upperp = p->upperp;
 		fa.changed = nullptr;
 		fa.dinv_scratch = nullptr;
-		if (pat.bs == 8 && !pat.rowmajor)
-			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * 64);
+		if (pat.bs >= 5)
+			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * pat.bs * pat.bs);
 
 		const long ngroups = (long)pat.nbrows + 8;
 		if (precinfo) {

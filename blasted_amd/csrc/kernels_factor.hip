@@ -175,13 +175,20 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 			if (active)
 				resid += fabs(s);
 		} else if (irow > col) {
-			const double dv = active ? a.in[(long)a.pat.diagind[col] * BS2 + e] : 0.0;
 			double res;
-			if (BS == 1)
-				res = s / dv;
-			else {
-				const double inv = group_inverse<BS, BSP>(dv, gbase, r, c);
+			if (BS >= 5 && a.dinv_scratch) {
+				// bs >= 5: the diagonal blocks of the sweep's input iterate were inverted by the per-sweep
+				// pre-pass (launch_factor_sweep); kernels_factor8.hip explains why this is the same map
+				const double inv = active ? a.dinv_scratch[(long)col * BS2 + e] : 0.0;
 				res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
+			} else {
+				const double dv = active ? a.in[(long)a.pat.diagind[col] * BS2 + e] : 0.0;
+				if (BS == 1)
+					res = s / dv;
+				else {
+					const double inv = group_inverse<BS, BSP>(dv, gbase, r, c);
+					res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
+				}
 			}
 			if (active) {
 				if (a.changed && !(a.out[(long)jpos * BS2 + e] == res))
@@ -506,6 +513,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 		return;
 	if (launch_factor8(a, a.dinv_scratch, s))
 		return;
+	if (a.pat.bs >= 5 && a.dinv_scratch)
+		launch_invert_diag_blocks(a.pat, a.in, 1, a.dinv_scratch, 0, s);
 	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
 		hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, false>), dim3(grid), dim3(256), 0, s, a,
