@@ -26,6 +26,7 @@ SYMBOLS = [
     "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
     "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
+    "blasted_hip_gs_relax",
 ]
 
 _lib = None
@@ -67,6 +68,7 @@ def lib():
         _lib.blasted_hip_jacobi_apply.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_sgs_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
         _lib.blasted_hip_sgs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
+        _lib.blasted_hip_gs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
         for nm in ("iluvals", "dblocks", "scale", "ytemp"):
@@ -219,6 +221,12 @@ class Prec:
         """x is updated in place and returned."""
         b = self._prep(b)
         _check(lib().blasted_hip_sgs_relax(self._h, _ptr(b), _ptr(x), int(maxits), int(mode), _loc(b)))
+        return x
+
+    def gs_relax(self, b, x, nsweeps, mode=ASYNC):
+        """Forward (ascending) relaxation sweeps; x is updated in place and returned."""
+        b = self._prep(b)
+        _check(lib().blasted_hip_gs_relax(self._h, _ptr(b), _ptr(x), int(nsweeps), int(mode), _loc(b)))
         return x
 
     # -- SpMV

@@ -806,7 +806,10 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 	});
 }
 
-int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int mode, int loc)
+// x_i <- D_i^-1 (b_i - sum_{j != i} A_ij x_j) in place, `maxits` steps of one ascending pass and, when
+// `symmetric`, one descending pass
+static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits, int mode, int loc,
+                      bool symmetric)
 {
 	return guarded([&] {
 		use_device(p);
@@ -814,7 +817,7 @@ int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int ma
 		check_mode(mode);
 		need_jacobi(p);
 		if (!b || !x || maxits < 0)
-			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_relax: null vector or negative iteration count");
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "relaxation: null vector or negative iteration count");
 		const long n = p->n();
 		const size_t nbytes = sizeof(double) * (size_t)n;
 		const double *db = in_vec(p, b, loc, 0);
@@ -831,9 +834,8 @@ int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int ma
 		a.rhs = db;
 		double *other = (mode == BLASTED_HIP_JACOBI_SYNC) ? ensure(p->tmp[0], n) : nullptr;
 		double *cur = dx;
-		// src/solverops_sgs.cpp:96-115: per step an ascending and a descending pass
 		for (int step = 0; step < maxits; step++) {
-			for (int dir = 0; dir < 2; dir++) {
+			for (int dir = 0; dir < (symmetric ? 2 : 1); dir++) {
 				a.descending = dir;
 				double *o = (mode == BLASTED_HIP_JACOBI_SYNC) ? (cur == dx ? other : dx) : dx;
 				Phase ph(p, dir);
@@ -849,6 +851,18 @@ int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int ma
 			BHIP_CHECK(hipMemcpyAsync(dx, cur, nbytes, hipMemcpyDeviceToDevice, p->stream));
 		finish_out(p, x, dx, loc);
 	});
+}
+
+// src/solverops_sgs.cpp:96-115: per step an ascending and a descending pass
+int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int mode, int loc)
+{
+	return relax_impl(p, b, x, maxits, mode, loc, true);
+}
+
+// src/relaxation_chaotic.cpp:21-70: ascending passes only
+int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsweeps, int mode, int loc)
+{
+	return relax_impl(p, b, x, nsweeps, mode, loc, false);
 }
 
 /* ---- SpMV --------------------------------------------------------------------------------- */

@@ -3,7 +3,7 @@
 //
 // Type strings and dispatch rules are the reference's: `ilu0` -> async factor + async apply,
 // `seqilu0` -> sequential both, `sfilu0` -> sequential factor, `sapilu0` -> sequential apply; bs == 1
-// always selects the scalar operators.  Types outside the preconditioner-apply hot path (gs, cscbgs,
+// always selects the scalar operators.  Types outside the preconditioner-apply hot path (cscbgs,
 // level_sgs, async_level_ilu0) are recognised by solverTypeFromString but create_preconditioner
 // rejects them with std::invalid_argument on this backend.
 #pragma once

@@ -5,6 +5,7 @@
 //   Preconditioner, SRPreconditioner, NoPreconditioner   include/solverops_base.hpp:31-106
 //   JacobiSRPreconditioner, BJacobiSRPreconditioner      include/solverops_jacobi.hpp
 //   AsyncSGS_SRPreconditioner, AsyncBlockSGS_SRPreconditioner   include/solverops_sgs.hpp:23-121
+//   ChaoticRelaxation, ChaoticBlockRelaxation                   include/relaxation_chaotic.hpp:20-95
 //   AsyncILU0_SRPreconditioner, AsyncBlockILU0_SRPreconditioner include/solverops_ilu0.hpp:23-169
 //   SRMatrixView, BSRMatrixView, CSRMatrixView (apply / gemv3 only)  include/blockmatrices.hpp:27-160
 // What is different is where the work happens: every compute()/apply()/apply_relax()/gemv3() forwards to
@@ -226,6 +227,35 @@ public:
 	                          const ApplyInit apply_inittype, const int threadchunksize)
 	    : AsyncBlockSGS_SRPreconditioner<scalar, index, 1, ColMajor>(std::move(matrix), napplysweeps,
 	                                                                   apply_inittype, threadchunksize)
+	{
+	}
+};
+
+/// Chaotic (asynchronous forward Gauss-Seidel) block relaxation, the `gs` type
+/// (include/relaxation_chaotic.hpp:20-55).  apply() and apply_relax() both relax in place: the output
+/// vector is also the initial guess, exactly as in the reference.
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class ChaoticBlockRelaxation : public BJacobiSRPreconditioner<scalar, index, bs, stor> {
+public:
+	ChaoticBlockRelaxation(SRMatrixStorage<const scalar, const index> &&matrix, const int napplysweeps,
+	                       const int thread_chunk_size);
+	bool relaxationAvailable() const { return true; }
+	void apply(const scalar *const b, scalar *const __restrict x) const;
+	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
+
+protected:
+	using SRPreconditioner<scalar, index>::op;
+	using SRPreconditioner<scalar, index>::solveparams;
+	const int napplysweeps;
+	const int thread_chunk_size;
+};
+
+template <typename scalar, typename index>
+class ChaoticRelaxation : public ChaoticBlockRelaxation<scalar, index, 1, ColMajor> {
+public:
+	ChaoticRelaxation(SRMatrixStorage<const scalar, const index> &&matrix, const int napplysweeps,
+	                  const int thread_chunk_size)
+	    : ChaoticBlockRelaxation<scalar, index, 1, ColMajor>(std::move(matrix), napplysweeps, thread_chunk_size)
 	{
 	}
 };

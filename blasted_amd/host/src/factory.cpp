@@ -40,8 +40,8 @@ bool ilu_threading(const BlastedSolverType t, bool &tf, bool &ta)
 [[noreturn]] void not_on_this_backend(const char *what)
 {
 	throw std::invalid_argument(std::string("BLASTed(HIP): preconditioner type '") + what +
-	                            "' is outside the MI355X backend's scope (jacobi, sgs, ilu0, seqilu0, "
-	                            "sfilu0, sapilu0, none are available)");
+	                            "' is outside the MI355X backend's scope (jacobi, gs, sgs, ilu0, "
+	                            "seqilu0, sfilu0, sapilu0, none are available)");
 }
 
 }  // namespace
@@ -62,7 +62,9 @@ SRPreconditioner<scalar, index> *SRFactory<scalar, index>::create_srprecondition
 		return new AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>(
 		    std::move(mat), opts.napplysweeps, opts.apply_inittype, opts.thread_chunk_size);
 	case BLASTED_NO_PREC: return new NoPreconditioner<scalar, index>(std::move(mat), bs);
-	case BLASTED_GS: not_on_this_backend("gs");
+	case BLASTED_GS:
+		return new ChaoticBlockRelaxation<scalar, index, bs, stor>(std::move(mat), opts.napplysweeps,
+		                                                           opts.thread_chunk_size);
 	case BLASTED_LEVEL_SGS: not_on_this_backend("level_sgs");
 	case BLASTED_ASYNC_LEVEL_ILU0: not_on_this_backend("async_level_ilu0");
 	default: throw std::invalid_argument("Invalid preconditioner!");
@@ -89,7 +91,9 @@ SRFactory<scalar, index>::create_preconditioner(SRMatrixStorage<const scalar, co
 			return new AsyncSGS_SRPreconditioner<scalar, index>(std::move(mat), opts.napplysweeps,
 			                                                    opts.apply_inittype, opts.thread_chunk_size);
 		case BLASTED_NO_PREC: return new NoPreconditioner<scalar, index>(std::move(mat), 1);
-		case BLASTED_GS: not_on_this_backend("gs");
+		case BLASTED_GS:
+			return new ChaoticRelaxation<scalar, index>(std::move(mat), opts.napplysweeps,
+			                                            opts.thread_chunk_size);
 		case BLASTED_CSC_BGS: not_on_this_backend("cscbgs");
 		case BLASTED_LEVEL_SGS: not_on_this_backend("level_sgs");
 		case BLASTED_ASYNC_LEVEL_ILU0: not_on_this_backend("async_level_ilu0");

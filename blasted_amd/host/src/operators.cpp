@@ -301,6 +301,36 @@ void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax_device
 	                                         HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
 }
 
+// ------------------------------------------------------------------------------- chaotic relaxation (gs)
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+ChaoticBlockRelaxation<scalar, index, bs, stor>::ChaoticBlockRelaxation(
+    SRMatrixStorage<const scalar, const index> &&matrix, const int nas, const int tcs)
+    : BJacobiSRPreconditioner<scalar, index, bs, stor>(std::move(matrix)), napplysweeps{nas},
+      thread_chunk_size{tcs}
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply(const scalar *const b,
+                                                            scalar *const __restrict x) const
+{
+	if (!op)
+		throw std::runtime_error("chaotic relaxation: apply() before compute()");
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, napplysweeps, HipOperator::sweep_mode(),
+	                                        BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply_relax(const scalar *const b,
+                                                                  scalar *const __restrict x) const
+{
+	if (!op)
+		throw std::runtime_error("chaotic relaxation: apply_relax() before compute()");
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, solveparams.maxits, HipOperator::sweep_mode(),
+	                                        BLASTED_HIP_HOST));
+}
+
 // ------------------------------------------------------------------------------- (block-)ILU(0)
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
@@ -374,6 +404,7 @@ void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const
 #define BLASTED_INSTANTIATE(BS, STOR)                                      \
 	template class BJacobiSRPreconditioner<double, int, BS, STOR>;         \
 	template class AsyncBlockSGS_SRPreconditioner<double, int, BS, STOR>;  \
+	template class ChaoticBlockRelaxation<double, int, BS, STOR>;          \
 	template class AsyncBlockILU0_SRPreconditioner<double, int, BS, STOR>;
 
 BLASTED_INSTANTIATE(1, ColMajor)
@@ -392,6 +423,7 @@ BLASTED_INSTANTIATE(8, RowMajor)
 
 template class JacobiSRPreconditioner<double, int>;
 template class AsyncSGS_SRPreconditioner<double, int>;
+template class ChaoticRelaxation<double, int>;
 template class AsyncILU0_SRPreconditioner<double, int>;
 
 }  // namespace blasted

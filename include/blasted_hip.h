@@ -120,6 +120,11 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int mode,
                           int loc);
 
+/* Chaotic[Block]Relaxation::apply / apply_relax (the `gs` type), src/relaxation_chaotic.cpp:21-70,
+ * 92-125: nsweeps ascending passes of the same row update; x is the initial guess and the result. */
+int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsweeps, int mode,
+                         int loc);
+
 /* ---- SpMV --------------------------------------------------------------------------------- */
 
 /* BLAS_BSR::matrix_apply / BLAS_CSR::matrix_apply, src/blas/matvecs.cpp:26-48,78-92: y = A x */

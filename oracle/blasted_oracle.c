@@ -818,6 +818,14 @@ void orc_sgs_relax(const orc_bsr *m, const double *dblocks, int maxits, int chun
 	}
 }
 
+/* src/relaxation_chaotic.cpp:21-70,92-125 : forward passes only, x in/out */
+void orc_gs_relax(const orc_bsr *m, const double *dblocks, int nsweeps, int chunk, int mode,
+                  const double *b, double *x)
+{
+	sgs_vals sv = {m->vals, dblocks};
+	run_sweeps(m, relax_row_d, (const double *)&sv, b, x, nsweeps, chunk, mode, 0);
+}
+
 /* ---------------------------------------------------------------- SpMV */
 
 void orc_spmv(const orc_bsr *m, const double *x, double *y)

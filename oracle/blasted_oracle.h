@@ -93,6 +93,10 @@ void orc_sgs_apply(const orc_bsr *m, const double *dblocks, double *ytemp,
 void orc_sgs_relax(const orc_bsr *m, const double *dblocks, int maxits, int chunk, int mode,
                    const double *b, double *x);
 
+/* src/relaxation_chaotic.cpp:21-70,92-125 (the `gs` type): nsweeps ascending passes, x in/out */
+void orc_gs_relax(const orc_bsr *m, const double *dblocks, int nsweeps, int chunk, int mode,
+                  const double *b, double *x);
+
 /* src/blas/matvecs.cpp:26-108 */
 void orc_spmv(const orc_bsr *m, const double *x, double *y);
 void orc_gemv3(const orc_bsr *m, double a, const double *x, double b, const double *y, double *z);

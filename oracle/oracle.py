@@ -175,6 +175,14 @@ def sgs_relax(m, dblocks, b, x0=None, maxits=1, chunk=256, mode=GS_SERIAL):
     return x
 
 
+def gs_relax(m, dblocks, b, x0=None, nsweeps=1, chunk=256, mode=GS_SERIAL):
+    M = _Mat(m)
+    d, b = _f64(dblocks), _f64(b)
+    x = np.zeros(M.n) if x0 is None else _f64(x0).copy()
+    lib().orc_gs_relax(M.ref, _ptr(d), int(nsweeps), int(chunk), int(mode), _ptr(b), _ptr(x))
+    return x
+
+
 def spmv(m, x):
     M = _Mat(m)
     x = _f64(x)

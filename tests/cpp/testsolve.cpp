@@ -182,6 +182,7 @@ static SolveInfo richardson(const SRMatrixView<double, int> &A, const Preconditi
 		A.gemv3(-1.0, x.data(), 1.0, rhs.data(), s.data());
 		rel = std::sqrt(dot(s, s)) / bnorm;
 		if (rel < tol) break;
+		std::fill(d.begin(), d.end(), 0.0);  // relaxations (gs) read the output vector as their initial guess
 		M.apply(s.data(), d.data());
 		for (size_t i = 0; i < n; i++) x[i] += d[i];
 		step++;

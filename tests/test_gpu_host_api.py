@@ -28,6 +28,7 @@ CASES = [
     ("ThreadedBSR4ILU0Colmajor", "2dcyl1", ["--preconditioner_type", "ilu0", "--mat_type", "bsr", "--build_sweeps", "10", "--apply_sweeps", "15"], 1e-10, 1e-8, 200),
     ("BSR4SeqILU0Colmajor", "2dcyl1", ["--preconditioner_type", "seqilu0", "--mat_type", "bsr"], 1e-10, 1e-8, 200),
     ("BSR4SapILU0Colmajor", "2dcyl1", ["--preconditioner_type", "sapilu0", "--mat_type", "bsr", "--build_sweeps", "12"], 1e-10, 1e-8, 200),
+    ("BSR4RichardsonGS", "2dcyl1", ["--solver_type", "richardson", "--preconditioner_type", "gs", "--mat_type", "bsr", "--apply_sweeps", "10"], 1e-8, 1e-5, 2000),
     ("BSR4RichardsonSGS", "2dcyl1", ["--solver_type", "richardson", "--preconditioner_type", "sgs", "--mat_type", "bsr", "--apply_sweeps", "15"], 1e-8, 1e-5, 2000),
 ]
 
@@ -39,7 +40,7 @@ def test_native_solve(name, mat, extra, tol, testtol, maxiter):
     floor = 2e-9 if mat == "msc00726" else 0.0
     args = [DRIVER, "--fact_init_type", "init_original", "--apply_init_type", "init_zero",
             "--mat_file", os.path.join(G, mat + ".mtx"), "--b_file", os.path.join(G, mat + "_b.mtx"),
-            "--x_file", os.path.join(G, mat + "_x.mtx"), "--solver_tol", repr(tol * 1e-4 if name != "BSR4RichardsonSGS" else tol),
+            "--x_file", os.path.join(G, mat + "_x.mtx"), "--solver_tol", repr(tol * 1e-4 if "Richardson" not in name else tol),
             "--test_tol", repr(max(testtol, floor)), "--max_iter", str(2 * maxiter)] + extra
     r = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -398,6 +398,28 @@ def test_medium_poisson_64_against_oracle():
     p.close()
 
 
+# ---------------------------------------------------------------------------- chaotic relaxation (gs)
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4"])
+def test_gs_relaxation_matches_oracle(golden, case):
+    """The `gs` type, src/relaxation_chaotic.cpp:21-70: forward passes only, x is guess and result."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    b = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    for x0 in (np.zeros(n), 0.2 * np.cos(np.arange(n))):
+        x = p.gs_relax(b, x0.copy(), 3, mode=capi.JACOBI_SYNC)
+        assert rel(x, O.gs_relax(m, gd, b, x0=x0, nsweeps=3, mode=O.JACOBI_SYNC)) < 1e-11
+    # async forward sweeps converge to one serial forward Gauss-Seidel pass repeated: compare fixed points
+    xs = O.gs_relax(m, gd, b, nsweeps=3000, mode=O.GS_SERIAL)
+    xa = p.gs_relax(b, np.zeros(n), 6000, mode=capi.ASYNC)
+    if np.all(np.isfinite(xs)) and np.abs(xs).max() < 1e6:
+        assert rel(xa, xs) < 1e-8
+    p.close()
+
+
 # ---------------------------------------------------------------------------- sequential variants
 
 @pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "msc_csr", "poisson16_bs4", "poisson12_bs5", "random_bs4"])
