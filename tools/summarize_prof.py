@@ -46,11 +46,21 @@ def main(tag, op="ilu_apply"):
         if "FETCH_SIZE_KB_avg" in d and "WRITE_SIZE_KB_avg" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_KB_avg"] + d["WRITE_SIZE_KB_avg"]) * 1024.0
     json.dump(pmc, open(os.path.join(prof, "%s_pmc.json" % tag), "w"), indent=1)
-    # bench.py reads the dominant kernel's traffic from profiles/traffic.json
-    dom = [k for k in pmc if "sweep4_kernel<1, 1, 1" in k or "sweep_kernel<4, false, 1, 1, 1>" in k]
+    # bench.py reads the dominant kernel's traffic from profiles/traffic.json: the kernel bench.py's
+    # roofline object is quoted on (the descending/upper sweep for the apply ops), i.e. the bhip::
+    # sweep or factor kernel with the most launches in the FETCH pass, ties broken by traffic
+    want = {"ilu_apply": ("sweepw_kernel<4, 1,", "sweep_kernel<"), "sgs_apply": ("sweepw_kernel<4, 1,", "sweep_kernel<"),
+            "sgs_relax": ("sweepw_kernel<4, 2,", "sweep_kernel<"), "spmv": ("sweepw_kernel<4, 3,", "sweep_kernel<"),
+            "factor": ("factor4_kernel", "factor_sweep_kernel")}.get(op, ("sweepw_kernel",))
+    dom = []
+    for w in want:
+        dom = sorted([k for k in pmc if w in k and "hbm_bytes_per_launch" in pmc[k]],
+                     key=lambda k: (-pmc[k]["launches_FETCH_SIZE"], -pmc[k]["hbm_bytes_per_launch"]))
+        if dom:
+            break
     tf = os.path.join(prof, "traffic.json")
     cur = json.load(open(tf)) if os.path.exists(tf) else {}
-    if dom and "hbm_bytes_per_launch" in pmc[dom[0]]:
+    if dom:
         cur[op] = {"kernel": dom[0], "hbm_bytes_per_launch": pmc[dom[0]]["hbm_bytes_per_launch"], "from": tag}
         json.dump(cur, open(tf, "w"), indent=1)
     print(json.dumps(pmc, indent=1)[:3000])
