@@ -11,7 +11,7 @@ LIBPATH = os.path.join(HERE, "lib", "libblasted_hip.so")
 OK, EINVAL, ENODEV, ERUNTIME, ESTATE, ENOTIMPL = 0, 1, 2, 3, 4, 5
 COLMAJOR, ROWMAJOR = 0, 1
 HOST, DEVICE = 0, 1
-ASYNC, JACOBI_SYNC = 0, 1
+ASYNC, JACOBI_SYNC, LEVEL = 0, 1, 2
 INIT_F_ZERO, INIT_F_ORIGINAL, INIT_F_SGS, INIT_F_NONE = 0, 1, 2, 3
 INIT_A_ZERO, INIT_A_JACOBI, INIT_A_NONE = 0, 1, 2
 
@@ -26,7 +26,8 @@ SYMBOLS = [
     "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
     "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
-    "blasted_hip_gs_relax",
+    "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
+    "blasted_hip_get_levels",
 ]
 
 _lib = None
@@ -69,6 +70,9 @@ def lib():
         _lib.blasted_hip_sgs_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
         _lib.blasted_hip_sgs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
         _lib.blasted_hip_gs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
+        _lib.blasted_hip_level_schedule.argtypes = [vp]
+        _lib.blasted_hip_level_count.argtypes = [vp, C.POINTER(ci)]
+        _lib.blasted_hip_get_levels.argtypes = [vp, vp, vp, vp]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
         for nm in ("iluvals", "dblocks", "scale", "ytemp"):
@@ -228,6 +232,21 @@ class Prec:
         b = self._prep(b)
         _check(lib().blasted_hip_gs_relax(self._h, _ptr(b), _ptr(x), int(nsweeps), int(mode), _loc(b)))
         return x
+
+    # -- level schedule
+    def level_count(self):
+        n = C.c_int(0)
+        _check(lib().blasted_hip_level_count(self._h, C.byref(n)))
+        return n.value
+
+    def get_levels(self):
+        """-> (level_of_row[nbrows], rows_by_level[nbrows], level_ptr[nlevels+1]) int32 numpy arrays."""
+        nl = self.level_count()
+        lv = np.zeros(self.nbrows, dtype=np.int32)
+        rows = np.zeros(self.nbrows, dtype=np.int32)
+        ptr = np.zeros(nl + 1, dtype=np.int32)
+        _check(lib().blasted_hip_get_levels(self._h, lv.ctypes.data, rows.ctypes.data, ptr.ctypes.data))
+        return lv, rows, ptr
 
     # -- SpMV
     def spmv(self, x, out=None):

@@ -161,8 +161,15 @@ static void check_loc(int loc)
 
 static void check_mode(int mode)
 {
-	if (mode != BLASTED_HIP_ASYNC && mode != BLASTED_HIP_JACOBI_SYNC)
-		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC or BLASTED_HIP_JACOBI_SYNC");
+	if (mode != BLASTED_HIP_ASYNC && mode != BLASTED_HIP_JACOBI_SYNC && mode != BLASTED_HIP_LEVEL)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC, BLASTED_HIP_JACOBI_SYNC or BLASTED_HIP_LEVEL");
+}
+
+static const LevelSchedule &need_levels(blasted_hip_prec p)
+{
+	if (!p->levels.built)
+		build_level_schedule(p->pat, p->levels, p->stream);
+	return p->levels;
 }
 
 static SweepArgs base_args(blasted_hip_prec p)
@@ -182,37 +189,22 @@ static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post,
                           double *other, const double *first_in, int nsweeps, int mode, int kind)
 {
 	Phase ph(p, kind);
-	if (nsweeps < 0) {
-		// sequential variant: in-place sweeps until one sweep changes nothing.  The stationary point of
-		// the sweep map is the result of one in-order (serial) pass, bit for bit: every row is then
-		// computed by the same expression from the final values of the rows it depends on.
-		if (first_in && first_in != x)
+	if (nsweeps < 0 || mode == BLASTED_HIP_LEVEL) {
+		// exact in-order passes (sequential variants and the level-scheduled types): one launch per
+		// dependency level, in place.  A triangular pass reads only rows it has already written, so the
+		// initial content of x is never used and repeating it changes nothing: one pass is enough.
+		const bool triangular = part == PART_LOWER || part == PART_UPPER;
+		const int passes = nsweeps < 0 ? 1 : (triangular && nsweeps > 1 ? 1 : nsweeps);
+		const LevelSchedule &ls = need_levels(p);
+		if (!triangular && first_in && first_in != x && passes > 0)
 			BHIP_CHECK(hipMemcpyAsync(x, first_in, sizeof(double) * (size_t)p->n(), hipMemcpyDeviceToDevice,
 			                          p->stream));
-		constexpr int BATCH = 8;
-		if (!p->flags)
-			p->flags = dev_alloc<int>(BATCH);
-		const long cap = (long)p->pat.nbrows + 2;
-		int hflags[BATCH];
-		bool stationary = false;
-		for (long done = 0; done < cap && !stationary; done += BATCH) {
-			BHIP_CHECK(hipMemsetAsync(p->flags, 0, sizeof(int) * BATCH, p->stream));
-			for (int s = 0; s < BATCH; s++) {
-				a.xin = x;
-				a.xout = x;
-				a.changed = p->flags + s;
-				launch_sweep(a, part, post, dsrc, p->stream);
-				ph.launches++;
-			}
-			BHIP_CHECK(hipMemcpyAsync(hflags, p->flags, sizeof(int) * BATCH, hipMemcpyDeviceToHost, p->stream));
-			BHIP_CHECK(hipStreamSynchronize(p->stream));
-			for (int s = 0; s < BATCH; s++)
-				if (!hflags[s])
-					stationary = true;
-		}
+		a.xin = x;
+		a.xout = x;
+		a.changed = nullptr;
+		for (int s = 0; s < passes; s++)
+			ph.launches += launch_level_sweep(a, part, post, dsrc, ls, p->stream);
 		ph.done();
-		if (!stationary)
-			BHIP_FAIL(BLASTED_HIP_ERUNTIME, "sequential sweeps did not become stationary (NaN in the iterate?)");
 		return x;
 	}
 	double *cur = x;
@@ -309,6 +301,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		}
 		dev_free(p->red);
 		dev_free(p->flags);
+		free_level_schedule(p->levels);
 		if (p->own_stream)
 			(void)hipStreamDestroy(p->stream);
 		delete p;
@@ -460,6 +453,9 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
+		if (mode == BLASTED_HIP_LEVEL)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
+			                              "points; the exact factorisation is nbuildsweeps < 0");
 		if (fact_init < BLASTED_HIP_INIT_F_ZERO || fact_init > BLASTED_HIP_INIT_F_NONE)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "Factor initialization not recongnized!");
 		const Pattern &pat = p->pat;
@@ -602,7 +598,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		if (!r || !z)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_apply: null vector");
 		if (napplysweeps < 0)
-			mode = BLASTED_HIP_ASYNC;  // sequential variant: always in place
+			mode = BLASTED_HIP_LEVEL;  // sequential variant: one exact in-order pass
 		const long n = p->n();
 		const size_t nbytes = sizeof(double) * (size_t)n;
 		const double *dr = in_vec(p, r, loc, 0);
@@ -738,7 +734,7 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		if (!r || !z)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_apply: null vector");
 		if (napplysweeps < 0)
-			mode = BLASTED_HIP_ASYNC;
+			mode = BLASTED_HIP_LEVEL;
 		if (apply_init < BLASTED_HIP_INIT_A_ZERO || apply_init > BLASTED_HIP_INIT_A_NONE)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "Apply initialization not recongnized!");
 		const long n = p->n();
@@ -841,8 +837,13 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 				Phase ph(p, dir);
 				a.xin = cur;
 				a.xout = o;
-				launch_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, p->stream);
-				ph.launches = 1;
+				if (mode == BLASTED_HIP_LEVEL)  // exact ascending / descending Gauss-Seidel pass
+					ph.launches = launch_level_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, need_levels(p),
+					                                 p->stream);
+				else {
+					launch_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, p->stream);
+					ph.launches = 1;
+				}
 				ph.done();
 				cur = o;
 			}
@@ -863,6 +864,45 @@ int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int ma
 int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsweeps, int mode, int loc)
 {
 	return relax_impl(p, b, x, nsweeps, mode, loc, false);
+}
+
+/* ---- level schedule -------------------------------------------------------------------------- */
+
+int blasted_hip_level_schedule(blasted_hip_prec p)
+{
+	return guarded([&] {
+		use_device(p);
+		need_pattern(p);
+		need_levels(p);
+	});
+}
+
+int blasted_hip_level_count(blasted_hip_prec p, int *nlevels)
+{
+	return guarded([&] {
+		use_device(p);
+		need_pattern(p);
+		if (!nlevels)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "level_count: null output");
+		*nlevels = need_levels(p).nlevels;
+	});
+}
+
+int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr)
+{
+	return guarded([&] {
+		use_device(p);
+		need_pattern(p);
+		const LevelSchedule &ls = need_levels(p);
+		const size_t nb = sizeof(int) * (size_t)p->pat.nbrows;
+		if (level_of_row && nb)
+			BHIP_CHECK(hipMemcpyAsync(level_of_row, ls.level, nb, hipMemcpyDeviceToHost, p->stream));
+		if (rows_by_level && nb)
+			BHIP_CHECK(hipMemcpyAsync(rows_by_level, ls.rows, nb, hipMemcpyDeviceToHost, p->stream));
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+		if (level_ptr)
+			std::memcpy(level_ptr, ls.ptr.data(), sizeof(int) * ls.ptr.size());
+	});
 }
 
 /* ---- SpMV --------------------------------------------------------------------------------- */

@@ -70,6 +70,16 @@ struct SweepArgs {
 	int *changed;           // optional flag: set to 1 if any stored value differs from the old one
 };
 
+// Level schedule of a pattern (kernels_level.hip): rows sorted by dependency depth
+struct LevelSchedule {
+	bool built = false;
+	int nlevels = 0;
+	long build_passes = 0;
+	int *rows = nullptr;   // device, nbrows: rows ordered by (level, row)
+	int *level = nullptr;  // device, nbrows: level of each row
+	std::vector<int> ptr;  // host, nlevels + 1: level l = rows[ptr[l] .. ptr[l+1])
+};
+
 struct FactorArgs {
 	Pattern pat;
 	const double *avals;    // original matrix values
@@ -88,6 +98,11 @@ bool sweep_offsets_fit(const Pattern &pat);
 // kernels_sweepw.hip (tuned bs=4/8 column-major path; false = not covered, use the generic family)
 bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepw_variant(const char *spec);
+// kernels_level.hip (exact in-order passes, one launch per dependency level)
+void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
+void free_level_schedule(LevelSchedule &ls);
+int launch_level_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
+                       hipStream_t s);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);
@@ -151,6 +166,8 @@ struct blasted_hip_prec_s {
 	double *stage[3] = {nullptr, nullptr, nullptr};  // n-vectors: device copies of host vectors
 	double *red = nullptr;                           // small reduction scratch
 	int *flags = nullptr;                            // per-sweep 'changed' flags (sequential variants)
+
+	bhip::LevelSchedule levels;
 
 	bhip::Timing timing;
 

@@ -133,6 +133,48 @@ def random_bsr(nbrows, bs, avg_offdiag=4, seed=12345, rowmajor=False, diag_weigh
             "vals": np.ascontiguousarray(vals.reshape(-1))}
 
 
+def permute_symmetric(m, rows):
+    """P A P^T of a host matrix dict: new block-row k is old block-row rows[k]; block columns are
+    renumbered with the inverse permutation and re-sorted inside each row (what a level / colouring
+    reordering does before the reference's computeLevels is used, src/levelschedule.cpp:13-72)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    nb, bs = int(m["nbrows"]), int(m["bs"])
+    inv = np.empty(nb, dtype=np.int64)
+    inv[rows] = np.arange(nb)
+    rp = np.asarray(m["browptr"], dtype=np.int64)
+    cnt = (rp[1:] - rp[:-1])[rows]
+    nrp = np.zeros(nb + 1, dtype=np.int64)
+    nrp[1:] = np.cumsum(cnt)
+    src = np.concatenate([np.arange(rp[i], rp[i + 1]) for i in rows]) if nb else np.zeros(0, dtype=np.int64)
+    newrow = np.repeat(np.arange(nb), cnt)
+    newcol = inv[np.asarray(m["bcolind"], dtype=np.int64)[src]]
+    order = np.lexsort((newcol, newrow))
+    src, newrow, newcol = src[order], newrow[order], newcol[order]
+    vals = np.asarray(m["vals"]).reshape(-1, bs * bs)[src]
+    diagind = np.nonzero(newrow == newcol)[0].astype(np.int32)
+    return {"nbrows": nb, "nnzb": int(m["nnzb"]), "bs": bs, "rowmajor": bool(m.get("rowmajor", False)),
+            "browptr": nrp.astype(np.int32), "bcolind": newcol.astype(np.int32), "diagind": diagind,
+            "vals": np.ascontiguousarray(vals.reshape(-1))}
+
+
+def dependency_levels(m):
+    """Longest-path depth of every block-row in the dependency DAG of the (symmetrised) pattern:
+    level(i) = 1 + max level(j) over j < i with A_ij or A_ji stored.  Host restatement (one in-order pass)
+    of what blasted_hip_level_schedule computes on the device."""
+    nb = int(m["nbrows"])
+    rp, ci = np.asarray(m["browptr"]), np.asarray(m["bcolind"])
+    level = np.zeros(nb, dtype=np.int32)
+    for i in range(nb):
+        cols = ci[rp[i]:rp[i + 1]]
+        lo = cols[cols < i]
+        if lo.size:
+            level[i] = max(level[i], level[lo].max() + 1)
+        hi = cols[cols > i]
+        if hi.size:
+            level[hi] = np.maximum(level[hi], level[i] + 1)
+    return level
+
+
 # ----------------------------------------------------------------------------- device generation
 
 def poisson3d_device(n, bs, device, grid="uniform", chunk_rows=1 << 21):

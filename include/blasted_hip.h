@@ -47,8 +47,11 @@ enum { BLASTED_HIP_HOST = 0, BLASTED_HIP_DEVICE = 1 };
 
 /* sweep semantics.  ASYNC: in-place chaotic sweeps, one launch per sweep (the GPU counterpart of the
  * reference's `omp for schedule(dynamic) nowait`, src/solverops_ilu0.cpp:99-108).  JACOBI_SYNC:
- * double-buffered synchronous Jacobi sweeps, deterministic; used by the parity tests. */
-enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1 };
+ * double-buffered synchronous Jacobi sweeps, deterministic; used by the parity tests.  LEVEL: every
+ * sweep is one exact in-order pass, run as one launch per dependency level (the reference's
+ * level-scheduled operators, src/solverops_levels_ilu0.cpp:58-105, src/solverops_levels_sgs.cpp:52-123);
+ * accepted by the apply / relaxation entry points, not by ilu0_factorize. */
+enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1, BLASTED_HIP_LEVEL = 2 };
 
 /* include/async_initialization_decl.hpp:15-34, same numeric values as FactInit / ApplyInit */
 enum { BLASTED_HIP_INIT_F_ZERO = 0, BLASTED_HIP_INIT_F_ORIGINAL = 1, BLASTED_HIP_INIT_F_SGS = 2,
@@ -97,9 +100,10 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 /* block_ilu0_apply, src/solverops_ilu0.cpp:55-148 ; scalar_ilu0_apply, :239-321.
  * z = S U^-1 L^-1 S r by napplysweeps lower sweeps then napplysweeps upper sweeps.
  * apply_init other than ZERO / JACOBI -> BLASTED_HIP_EINVAL (the reference throws, :125-126).
- * A negative sweep count (BLASTED_SEQUENTIAL_SYMBOL) in factorize / apply selects the reference's
- * sequential variants (threadedfactor / threadedapply = false): sweeps are repeated in place until one
- * changes nothing, which is bit for bit the result of one in-order serial pass. */
+ * A negative sweep count (BLASTED_SEQUENTIAL_SYMBOL) selects the reference's sequential variants
+ * (threadedfactor / threadedapply = false), i.e. the result of one in-order serial pass: apply runs one
+ * level-scheduled pass (mode LEVEL); factorize repeats in-place sweeps until one changes nothing, which
+ * is the serial result bit for bit. */
 int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
                            int apply_init, int mode, int loc);
 
@@ -124,6 +128,17 @@ int blasted_hip_sgs_relax(blasted_hip_prec p, const double *b, double *x, int ma
  * 92-125: nsweeps ascending passes of the same row update; x is the initial guess and the result. */
 int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsweeps, int mode,
                          int loc);
+
+/* ---- level schedule ------------------------------------------------------------------------ */
+
+/* Dependency levels of the pattern (the role of computeLevels, src/levelschedule.cpp:13-72, without
+ * its need for a level-ordered matrix): level(i) = 1 + max level(j) over j < i coupled to i.  Built
+ * lazily by the first LEVEL-mode call; this entry point builds it eagerly (once per pattern). */
+int blasted_hip_level_schedule(blasted_hip_prec p);
+int blasted_hip_level_count(blasted_hip_prec p, int *nlevels);
+/* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
+ * inside a level), level_ptr[nlevels+1] */
+int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr);
 
 /* ---- SpMV --------------------------------------------------------------------------------- */
 

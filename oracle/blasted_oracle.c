@@ -826,6 +826,110 @@ void orc_gs_relax(const orc_bsr *m, const double *dblocks, int nsweeps, int chun
 	run_sweeps(m, relax_row_d, (const double *)&sv, b, x, nsweeps, chunk, mode, 0);
 }
 
+/* ---------------------------------------------------------------- level scheduling */
+
+/* computeLevels, src/levelschedule.cpp:13-72.  levels[] receives the boundaries (levels[0] = 0,
+ * level l = rows [levels[l], levels[l+1])), capacity nbrows+1 entries; returns the number of levels, or
+ * -1 where the reference throws "Faulty dependency list!" (structurally non-symmetric pattern).
+ * The reference keeps a std::list of remaining dependencies per row and erases entries; here an erased
+ * entry is a flag on the stored position and front() is the first unflagged entry of the row. */
+int orc_compute_levels(const orc_bsr *m, int *levels)
+{
+	const int nb = m->nbrows;
+	char *erased = (char *)calloc((size_t)m->browptr[nb] + 1, 1);
+	int *front = (int *)malloc(sizeof(int) * ((size_t)nb + 1));
+	for (int i = 0; i < nb; i++)
+		front[i] = m->browptr[i];
+	int inode = 0, nlevels = 0, rc = 0;
+	levels[0] = 0;
+	while (inode < nb && rc == 0) {
+		/* 1. consecutive nodes whose smallest remaining dependency is not below themselves */
+		while (inode < nb) {
+			int f = front[inode];
+			while (f < m->browptr[inode + 1] && erased[f])
+				f++;
+			front[inode] = f;
+			if (f < m->browptr[inode + 1] && m->bcolind[f] < inode)
+				break;
+			inode++;
+		}
+		levels[++nlevels] = inode;
+		/* 2. remove the nodes of this level from their neighbours' dependency lists */
+		for (int jnode = levels[nlevels - 1]; jnode < inode && rc == 0; jnode++)
+			for (int jj = m->browptr[jnode]; jj < m->browptr[jnode + 1]; jj++) {
+				const int nbr = m->bcolind[jj];
+				if (nbr == jnode || erased[jj])
+					continue; /* a node already erased from this list is no longer iterated over */
+				const int pos = inner_search(m->bcolind, m->browptr[nbr], m->browptr[nbr + 1], jnode);
+				if (pos < 0 || erased[pos]) {
+					rc = -1;
+					break;
+				}
+				erased[pos] = 1;
+			}
+		if (levels[nlevels] == levels[nlevels - 1] && inode < nb) {
+			rc = -1; /* no progress: cannot happen for a valid pattern */
+		}
+	}
+	free(erased);
+	free(front);
+	return rc ? rc : nlevels;
+}
+
+/* one level-scheduled pass: `omp parallel for` over the rows of each level, levels in ascending or
+ * descending order (src/solverops_levels_ilu0.cpp:81-99, src/solverops_levels_sgs.cpp:66-88) */
+static void run_level_pass(const orc_bsr *m, rowfn fn, const double *vals, const double *rhs, double *x,
+                           const int *levels, int nlevels, int descending)
+{
+	if (!descending) {
+		for (int l = 0; l < nlevels; l++) {
+#pragma omp parallel for default(shared)
+			for (int i = levels[l]; i < levels[l + 1]; i++)
+				fn(m, vals, i, rhs, x, x);
+		}
+	} else {
+		for (int l = nlevels; l > 0; l--) {
+#pragma omp parallel for default(shared)
+			for (int i = levels[l] - 1; i >= levels[l - 1]; i--)
+				fn(m, vals, i, rhs, x, x);
+		}
+	}
+}
+
+/* Async_Level_BlockILU0::apply / Async_Level_ILU0::apply, src/solverops_levels_ilu0.cpp:58-105,146-200 */
+void orc_level_ilu0_apply(const orc_bsr *m, const double *iluvals, const double *scale, double *ytemp,
+                          const int *levels, int nlevels, const double *r, double *z)
+{
+	const long n = (long)m->nbrows * m->bs;
+	for (long i = 0; i < n; i++)
+		z[i] = scale ? scale[i] * r[i] : r[i];
+	run_level_pass(m, lower_row_d, iluvals, z, ytemp, levels, nlevels, 0);
+	run_level_pass(m, upper_row_d, iluvals, ytemp, z, levels, nlevels, 1);
+	if (scale)
+		for (long i = 0; i < n; i++)
+			z[i] = z[i] * scale[i];
+}
+
+/* Level_BSGS::apply / Level_SGS::apply, src/solverops_levels_sgs.cpp:52-88,166-195 */
+void orc_level_sgs_apply(const orc_bsr *m, const double *dblocks, double *ytemp, const int *levels,
+                         int nlevels, const double *r, double *z)
+{
+	sgs_vals sv = {m->vals, dblocks};
+	run_level_pass(m, fgs_row_d, (const double *)&sv, r, ytemp, levels, nlevels, 0);
+	run_level_pass(m, bgs_row_d, (const double *)&sv, ytemp, z, levels, nlevels, 1);
+}
+
+/* Level_BSGS::apply_relax / Level_SGS::apply_relax, src/solverops_levels_sgs.cpp:90-123,197-223 */
+void orc_level_sgs_relax(const orc_bsr *m, const double *dblocks, const int *levels, int nlevels,
+                         int maxits, const double *b, double *x)
+{
+	sgs_vals sv = {m->vals, dblocks};
+	for (int step = 0; step < maxits; step++) {
+		run_level_pass(m, relax_row_d, (const double *)&sv, b, x, levels, nlevels, 0);
+		run_level_pass(m, relax_row_d, (const double *)&sv, b, x, levels, nlevels, 1);
+	}
+}
+
 /* ---------------------------------------------------------------- SpMV */
 
 void orc_spmv(const orc_bsr *m, const double *x, double *y)

@@ -97,6 +97,17 @@ void orc_sgs_relax(const orc_bsr *m, const double *dblocks, int maxits, int chun
 void orc_gs_relax(const orc_bsr *m, const double *dblocks, int nsweeps, int chunk, int mode,
                   const double *b, double *x);
 
+/* computeLevels, src/levelschedule.cpp:13-72: levels[0..nlevels] row-range boundaries (capacity
+ * nbrows+1); returns nlevels, or -1 where the reference throws "Faulty dependency list!" */
+int orc_compute_levels(const orc_bsr *m, int *levels);
+/* src/solverops_levels_ilu0.cpp:58-105,146-200 ; src/solverops_levels_sgs.cpp:52-123,166-223 */
+void orc_level_ilu0_apply(const orc_bsr *m, const double *iluvals, const double *scale, double *ytemp,
+                          const int *levels, int nlevels, const double *r, double *z);
+void orc_level_sgs_apply(const orc_bsr *m, const double *dblocks, double *ytemp, const int *levels,
+                         int nlevels, const double *r, double *z);
+void orc_level_sgs_relax(const orc_bsr *m, const double *dblocks, const int *levels, int nlevels,
+                         int maxits, const double *b, double *x);
+
 /* src/blas/matvecs.cpp:26-108 */
 void orc_spmv(const orc_bsr *m, const double *x, double *y);
 void orc_gemv3(const orc_bsr *m, double a, const double *x, double b, const double *y, double *z);

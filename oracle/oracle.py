@@ -183,6 +183,44 @@ def gs_relax(m, dblocks, b, x0=None, nsweeps=1, chunk=256, mode=GS_SERIAL):
     return x
 
 
+def compute_levels(m):
+    """computeLevels, src/levelschedule.cpp:13-72 -> int32 boundaries [nlevels+1]; ValueError where the
+    reference throws "Faulty dependency list!"."""
+    M = _Mat(m)
+    lv = np.zeros(M.nbrows + 2, dtype=np.int32)
+    nl = lib().orc_compute_levels(M.ref, _ptr(lv))
+    if nl < 0:
+        raise ValueError("Faulty dependency list!")
+    return lv[:nl + 1].copy()
+
+
+def level_ilu0_apply(m, iluvals, levels, r, scale=None):
+    M = _Mat(m)
+    ilu, r, lv = _f64(iluvals), _f64(r), _i32(levels)
+    z = np.zeros(M.n)
+    y = np.zeros(M.n)
+    sc = _f64(scale) if scale is not None else None
+    lib().orc_level_ilu0_apply(M.ref, _ptr(ilu), _ptr(sc), _ptr(y), _ptr(lv), int(lv.size - 1), _ptr(r), _ptr(z))
+    return z
+
+
+def level_sgs_apply(m, dblocks, levels, r):
+    M = _Mat(m)
+    d, r, lv = _f64(dblocks), _f64(r), _i32(levels)
+    z = np.zeros(M.n)
+    y = np.zeros(M.n)
+    lib().orc_level_sgs_apply(M.ref, _ptr(d), _ptr(y), _ptr(lv), int(lv.size - 1), _ptr(r), _ptr(z))
+    return z
+
+
+def level_sgs_relax(m, dblocks, levels, b, x0=None, maxits=1):
+    M = _Mat(m)
+    d, b, lv = _f64(dblocks), _f64(b), _i32(levels)
+    x = np.zeros(M.n) if x0 is None else _f64(x0).copy()
+    lib().orc_level_sgs_relax(M.ref, _ptr(d), _ptr(lv), int(lv.size - 1), int(maxits), _ptr(b), _ptr(x))
+    return x
+
+
 def spmv(m, x):
     M = _Mat(m)
     x = _f64(x)

@@ -1,0 +1,157 @@
+"""GPU parity tests of the level-scheduled (exact in-order) sweeps: the reference's `level_sgs` and
+`async_level_ilu0` types (src/solverops_levels_sgs.cpp, src/solverops_levels_ilu0.cpp) and the
+sequential apply variants.
+
+ * P0: the device level schedule equals the in-order host definition bit for bit, and the reference's
+   own computeLevels (src/levelschedule.cpp:13-72), run on the matrix renumbered level by level, returns
+   exactly the device's level boundaries.
+ * LEVEL-mode sweeps on the ORIGINAL ordering == the oracle's serial pass (rel <= 1e-12) and == the
+   reference's level-scheduled operators on the renumbered matrix, mapped back.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from blasted_amd import capi, workloads as W
+from test_gpu_parity import matrices, make_prec, rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16_csr", "poisson16_bs4",
+         "poisson12_bs5", "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5",
+         "random_bs4", "random_csr"]
+
+
+def one_sided(m):
+    """Drops the strictly-upper block of some coupled pairs: a structurally NON-symmetric pattern."""
+    nb, bs2 = m["nbrows"], m["bs"] ** 2
+    rp, ci = m["browptr"], m["bcolind"]
+    rows = np.repeat(np.arange(nb), rp[1:] - rp[:-1])
+    keep = ~((ci > rows) & ((rows + ci) % 3 == 0))
+    nrp = np.zeros(nb + 1, dtype=np.int64)
+    np.add.at(nrp, rows[keep] + 1, 1)
+    nrp = np.cumsum(nrp).astype(np.int32)
+    nci = ci[keep]
+    nrows = rows[keep]
+    out = dict(m)
+    out.update(nnzb=int(keep.sum()), browptr=nrp, bcolind=nci.astype(np.int32),
+               diagind=np.nonzero(nrows == nci)[0].astype(np.int32),
+               vals=np.ascontiguousarray(m["vals"].reshape(-1, bs2)[keep].reshape(-1)))
+    return out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_level_schedule_bit_exact(golden, case):
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    lv, rows, ptr = p.get_levels()
+    ref = W.dependency_levels(m)
+    assert np.array_equal(lv, ref)
+    # rows sorted by (level, row), boundaries consistent
+    order = np.lexsort((np.arange(m["nbrows"]), ref))
+    assert np.array_equal(rows, order.astype(np.int32))
+    assert ptr[0] == 0 and ptr[-1] == m["nbrows"] and np.all(np.diff(ptr) > 0)
+    assert np.array_equal(np.searchsorted(ref[order], np.arange(ptr.size - 1)), ptr[:-1])
+    # the reference's computeLevels on the level-ordered matrix finds the same boundaries
+    mp = W.permute_symmetric(m, rows)
+    assert np.array_equal(O.compute_levels(mp), ptr)
+    p.close()
+
+
+def test_level_schedule_nonsymmetric_pattern(golden):
+    m = one_sided(W.poisson3d(10, 4))
+    p = make_prec(m)
+    lv, rows, ptr = p.get_levels()
+    assert np.array_equal(lv, W.dependency_levels(m))
+    with pytest.raises(ValueError):  # the reference gives up on such a pattern
+        O.compute_levels(W.permute_symmetric(m, rows))
+    # exact passes all the same
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL)
+    gf = p.get_iluvals()
+    assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL)) < TOL
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    x = p.sgs_relax(r, np.zeros(n), 2, mode=capi.LEVEL)
+    assert rel(x, O.sgs_relax(m, gd, r, maxits=2, mode=O.GS_SERIAL)) < TOL
+    p.close()
+
+
+@pytest.mark.parametrize("scaling", [False, True])
+@pytest.mark.parametrize("case", CASES)
+def test_level_ilu0_apply(golden, case, scaling):
+    """async_level_ilu0: asynchronous factorisation, exact (level-scheduled) triangular solves."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    # two synchronous sweeps leave msc00726's factor non-finite: use the exact factor there
+    nb = -1 if case == "msc_csr" else 2
+    p.ilu0_factorize(nb, init=capi.INIT_F_ORIGINAL, usescale=scaling, mode=capi.JACOBI_SYNC)
+    gf = p.get_iluvals()
+    sc = p.get_scale() if scaling else None
+    z = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+    want = O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL, scale=sc)
+    assert rel(z, want) < TOL
+    # more sweeps or the sequential symbol change nothing: one pass is already exact
+    assert np.array_equal(p.ilu0_apply(r, 3, mode=capi.LEVEL), z)
+    assert np.array_equal(p.ilu0_apply(r, -1), z)
+    # the reference's level-scheduled operator on the level-ordered matrix, mapped back
+    lv, rows, ptr = p.get_levels()
+    try:
+        levels = O.compute_levels(W.permute_symmetric(m, rows))
+    except ValueError:
+        levels = None
+    if levels is not None:
+        mp = W.permute_symmetric(m, rows)
+        bs = m["bs"]
+        pp = make_prec(mp)
+        pp.ilu0_factorize(nb, init=capi.INIT_F_ORIGINAL, usescale=scaling, mode=capi.JACOBI_SYNC)
+        perm = (rows[:, None].astype(np.int64) * bs + np.arange(bs)[None, :]).reshape(-1)
+        zp = O.level_ilu0_apply(mp, pp.get_iluvals(), levels, r[perm], scale=pp.get_scale() if scaling else None)
+        assert rel(zp, z[perm]) < 1e-11
+        pp.close()
+    p.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_level_sgs(golden, case):
+    """level_sgs: exact symmetric Gauss-Seidel application and relaxation."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    bs = m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    z = p.sgs_apply(r, 1, mode=capi.LEVEL)
+    assert rel(z, O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL)) < TOL
+    assert np.array_equal(p.sgs_apply(r, -1), z)
+    x0 = 0.2 * np.cos(np.arange(n))
+    x = p.sgs_relax(r, x0.copy(), 3, mode=capi.LEVEL)
+    want = O.sgs_relax(m, gd, r, x0=x0, maxits=3, mode=O.GS_SERIAL)
+    if np.all(np.isfinite(want)) and np.abs(want).max() < 1e6:
+        assert rel(x, want) < 1e-11
+    xg = p.gs_relax(r, x0.copy(), 3, mode=capi.LEVEL)
+    wantg = O.gs_relax(m, gd, r, x0=x0, nsweeps=3, mode=O.GS_SERIAL)
+    if np.all(np.isfinite(wantg)) and np.abs(wantg).max() < 1e6:
+        assert rel(xg, wantg) < 1e-11
+    lv, rows, ptr = p.get_levels()
+    mp = W.permute_symmetric(m, rows)
+    perm = (rows[:, None].astype(np.int64) * bs + np.arange(bs)[None, :]).reshape(-1)
+    levels = O.compute_levels(mp)
+    gdp = O.jacobi_compute(mp)
+    assert rel(O.level_sgs_apply(mp, gdp, levels, r[perm]), z[perm]) < 1e-11
+    xr = O.level_sgs_relax(mp, gdp, levels, r[perm], x0=x0[perm], maxits=3)
+    if np.all(np.isfinite(want)) and np.abs(want).max() < 1e6:
+        assert rel(xr, x[perm]) < 1e-10
+    p.close()
+
+
+def test_level_mode_rejected_by_factorize(golden):
+    p = make_prec(W.poisson3d(6, 4))
+    with pytest.raises(capi.BlastedHipError):
+        p.ilu0_factorize(1, mode=capi.LEVEL)
+    p.close()

@@ -369,3 +369,39 @@ def test_diag_dominance_and_precinfo(golden):
     # tests/testutils.cpp:297-308: remainder < initial, < 1e-11 at one thread, diag dominance <= 1
     assert info[0] < info[1] and info[0] < 1e-11
     assert info[2] <= 1 and info[3] <= 1 and info[4] <= 1 and info[5] <= 1
+
+
+# ---------------------------------------------------------------------------- level scheduling
+
+@pytest.mark.parametrize("gen", ["poisson", "random"])
+def test_level_schedule_and_level_operators_equal_serial(gen):
+    """computeLevels (src/levelschedule.cpp:13-72) on a level-ordered matrix recovers the dependency
+    levels, and the level-scheduled operators (src/solverops_levels_*.cpp) equal the serial pass there --
+    the property the reference's level types rest on."""
+    m = W.poisson3d(9, 4) if gen == "poisson" else W.random_bsr(600, 5, avg_offdiag=6, seed=3)
+    bs = m["bs"]
+    lv = W.dependency_levels(m)
+    rows = np.lexsort((np.arange(m["nbrows"]), lv))
+    mp = W.permute_symmetric(m, rows)
+    levels = O.compute_levels(mp)
+    assert np.array_equal(levels[:-1], np.searchsorted(lv[rows], np.arange(lv.max() + 1)))
+    assert levels[-1] == m["nbrows"]
+    if gen == "poisson":
+        assert levels.size - 1 == 3 * 7 - 2  # wavefronts i+j+k of a 7^3 grid
+    # natural ordering: a row depends on its predecessor except at the start of a grid line, so the
+    # reference's consecutive-row levels hold one or two rows -- essentially sequential
+    if gen == "poisson":
+        assert O.compute_levels(m).size - 1 >= m["nbrows"] - 7 * 7
+    n = m["nbrows"] * bs
+    r = W.rhs_vector(n)
+    f = O.ilu0_factorize(mp, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert np.array_equal(O.level_ilu0_apply(mp, f, levels, r), O.ilu0_apply(mp, f, r, 1, mode=O.GS_SERIAL))
+    d = O.jacobi_compute(mp)
+    assert np.array_equal(O.level_sgs_apply(mp, d, levels, r), O.sgs_apply(mp, d, r, 1, mode=O.GS_SERIAL))
+    assert np.array_equal(O.level_sgs_relax(mp, d, levels, r, maxits=2), O.sgs_relax(mp, d, r, maxits=2, mode=O.GS_SERIAL))
+    # ... and the serial pass commutes with the renumbering (same L/U split), to rounding
+    perm = (rows[:, None].astype(np.int64) * bs + np.arange(bs)[None, :]).reshape(-1)
+    f0 = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    z0 = O.ilu0_apply(m, f0, r[np.argsort(perm)], 1, mode=O.GS_SERIAL)
+    zp = O.ilu0_apply(mp, f, r, 1, mode=O.GS_SERIAL)
+    assert np.abs(zp - z0[perm]).max() <= 1e-12 * np.abs(z0).max()
