@@ -6,6 +6,8 @@
 //   JacobiSRPreconditioner, BJacobiSRPreconditioner      include/solverops_jacobi.hpp
 //   AsyncSGS_SRPreconditioner, AsyncBlockSGS_SRPreconditioner   include/solverops_sgs.hpp:23-121
 //   ChaoticRelaxation, ChaoticBlockRelaxation                   include/relaxation_chaotic.hpp:20-95
+//   Level_BSGS, Level_SGS                                       include/solverops_levels_sgs.hpp:20-80
+//   Async_Level_BlockILU0, Async_Level_ILU0                     include/solverops_levels_ilu0.hpp:20-85
 //   AsyncILU0_SRPreconditioner, AsyncBlockILU0_SRPreconditioner include/solverops_ilu0.hpp:23-169
 //   SRMatrixView, BSRMatrixView, CSRMatrixView (apply / gemv3 only)  include/blockmatrices.hpp:27-160
 // What is different is where the work happens: every compute()/apply()/apply_relax()/gemv3() forwards to
@@ -309,6 +311,67 @@ public:
 	    : AsyncBlockILU0_SRPreconditioner<scalar, index, 1, ColMajor>(
 	          std::move(matrix), nbuildsweeps, napplysweeps, use_scaling, thread_chunk_size, fact_inittype,
 	          apply_inittype, threadedfactor, threadedapply, compute_preconditioner_info)
+	{
+	}
+};
+
+/// Level-scheduled (exact) block SGS, the `level_sgs` type (include/solverops_levels_sgs.hpp:20-50).
+/// The reference needs a matrix whose independent rows are consecutive (computeLevels); the device
+/// schedule is built from the dependency graph, so any ordering works and gives the serial result.
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class Level_BSGS : public BJacobiSRPreconditioner<scalar, index, bs, stor> {
+public:
+	Level_BSGS(SRMatrixStorage<const scalar, const index> &&matrix);
+	bool relaxationAvailable() const { return true; }
+	/// the first call also builds the level schedule
+	PrecInfo compute();
+	void apply(const scalar *const r, scalar *const __restrict z) const;
+	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
+	/// number of dependency levels (one kernel launch each per pass)
+	int numLevels() const;
+
+protected:
+	using SRPreconditioner<scalar, index>::op;
+	using SRPreconditioner<scalar, index>::solveparams;
+};
+
+template <typename scalar, typename index>
+class Level_SGS : public Level_BSGS<scalar, index, 1, ColMajor> {
+public:
+	Level_SGS(SRMatrixStorage<const scalar, const index> &&matrix)
+	    : Level_BSGS<scalar, index, 1, ColMajor>(std::move(matrix))
+	{
+	}
+};
+
+/// Asynchronous factorisation with level-scheduled (exact) triangular solves, the `async_level_ilu0`
+/// type (include/solverops_levels_ilu0.hpp:20-50).  Constructor arguments as in the reference:
+/// one apply "sweep", INIT_A_NONE, threaded apply.
+template <typename scalar, typename index, int bs, StorageOptions stor>
+class Async_Level_BlockILU0 : public AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor> {
+public:
+	Async_Level_BlockILU0(SRMatrixStorage<const scalar, const index> &&matrix, const int nbuildsweeps,
+	                      const bool use_scaling, const int thread_chunk_size, const FactInit fact_inittype,
+	                      const bool threadedfactor = true, const bool compute_remainder = false);
+	PrecInfo compute();
+	void apply(const scalar *const x, scalar *const __restrict y) const;
+	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
+	void apply_device(const scalar *const dr, scalar *const dz) const;
+	int numLevels() const;
+
+protected:
+	using SRPreconditioner<scalar, index>::op;
+};
+
+template <typename scalar, typename index>
+class Async_Level_ILU0 : public Async_Level_BlockILU0<scalar, index, 1, ColMajor> {
+public:
+	Async_Level_ILU0(SRMatrixStorage<const scalar, const index> &&matrix, const int nbuildsweeps,
+	                 const bool use_scaling, const int thread_chunk_size, const FactInit fact_inittype,
+	                 const bool threadedfactor = true, const bool compute_remainder = false)
+	    : Async_Level_BlockILU0<scalar, index, 1, ColMajor>(std::move(matrix), nbuildsweeps, use_scaling,
+	                                                        thread_chunk_size, fact_inittype, threadedfactor,
+	                                                        compute_remainder)
 	{
 	}
 };

@@ -41,7 +41,7 @@ bool ilu_threading(const BlastedSolverType t, bool &tf, bool &ta)
 {
 	throw std::invalid_argument(std::string("BLASTed(HIP): preconditioner type '") + what +
 	                            "' is outside the MI355X backend's scope (jacobi, gs, sgs, ilu0, "
-	                            "seqilu0, sfilu0, sapilu0, none are available)");
+	                            "seqilu0, sfilu0, sapilu0, level_sgs, async_level_ilu0, none are available)");
 }
 
 }  // namespace
@@ -65,8 +65,11 @@ SRPreconditioner<scalar, index> *SRFactory<scalar, index>::create_srprecondition
 	case BLASTED_GS:
 		return new ChaoticBlockRelaxation<scalar, index, bs, stor>(std::move(mat), opts.napplysweeps,
 		                                                           opts.thread_chunk_size);
-	case BLASTED_LEVEL_SGS: not_on_this_backend("level_sgs");
-	case BLASTED_ASYNC_LEVEL_ILU0: not_on_this_backend("async_level_ilu0");
+	case BLASTED_LEVEL_SGS: return new Level_BSGS<scalar, index, bs, stor>(std::move(mat));
+	case BLASTED_ASYNC_LEVEL_ILU0:
+		return new Async_Level_BlockILU0<scalar, index, bs, stor>(std::move(mat), opts.nbuildsweeps, opts.scale,
+		                                                          opts.thread_chunk_size, opts.fact_inittype,
+		                                                          true, opts.compute_precinfo);
 	default: throw std::invalid_argument("Invalid preconditioner!");
 	}
 }
@@ -95,8 +98,11 @@ SRFactory<scalar, index>::create_preconditioner(SRMatrixStorage<const scalar, co
 			return new ChaoticRelaxation<scalar, index>(std::move(mat), opts.napplysweeps,
 			                                            opts.thread_chunk_size);
 		case BLASTED_CSC_BGS: not_on_this_backend("cscbgs");
-		case BLASTED_LEVEL_SGS: not_on_this_backend("level_sgs");
-		case BLASTED_ASYNC_LEVEL_ILU0: not_on_this_backend("async_level_ilu0");
+		case BLASTED_LEVEL_SGS: return new Level_SGS<scalar, index>(std::move(mat));
+		case BLASTED_ASYNC_LEVEL_ILU0:
+			return new Async_Level_ILU0<scalar, index>(std::move(mat), opts.nbuildsweeps, opts.scale,
+			                                           opts.thread_chunk_size, opts.fact_inittype, true,
+			                                           opts.compute_precinfo);
 		default: throw std::invalid_argument("Invalid preconditioner!");
 		}
 	}

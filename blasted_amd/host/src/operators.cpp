@@ -397,6 +397,112 @@ void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const
 	throw std::runtime_error("ILU relaxation not implemented!");
 }
 
+// ------------------------------------------------------------------------------- level-scheduled types
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+Level_BSGS<scalar, index, bs, stor>::Level_BSGS(SRMatrixStorage<const scalar, const index> &&matrix)
+    : BJacobiSRPreconditioner<scalar, index, bs, stor>(std::move(matrix))
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+PrecInfo Level_BSGS<scalar, index, bs, stor>::compute()
+{
+	const bool first = !op;
+	PrecInfo info = BJacobiSRPreconditioner<scalar, index, bs, stor>::compute();
+	if (first)  // src/solverops_levels_sgs.cpp:43-47: levels once, with the first compute
+		HipOperator::check(blasted_hip_level_schedule(op->get()));
+	return info;
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Level_BSGS<scalar, index, bs, stor>::apply(const scalar *const r, scalar *const __restrict z) const
+{
+	if (!op)
+		throw std::runtime_error("level SGS: apply() before compute()");
+	// one exact forward and one exact backward pass: no initial guess is read (the reference does not
+	// initialise y or z either), so the init type only has to avoid an upload of z
+	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
+	                                         BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Level_BSGS<scalar, index, bs, stor>::apply_relax(const scalar *const b,
+                                                      scalar *const __restrict x) const
+{
+	if (!op)
+		throw std::runtime_error("level SGS: apply_relax() before compute()");
+	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, BLASTED_HIP_LEVEL,
+	                                         BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+int Level_BSGS<scalar, index, bs, stor>::numLevels() const
+{
+	if (!op)
+		throw std::runtime_error("level SGS: numLevels() before compute()");
+	int n = 0;
+	HipOperator::check(blasted_hip_level_count(op->get(), &n));
+	return n;
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+Async_Level_BlockILU0<scalar, index, bs, stor>::Async_Level_BlockILU0(
+    SRMatrixStorage<const scalar, const index> &&matrix, const int nbuildswp, const bool uscl, const int tcs,
+    const FactInit finit, const bool tf, const bool comp_rem)
+    : AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>(std::move(matrix), nbuildswp, 1, uscl, tcs, finit,
+                                                               INIT_A_NONE, tf, true, comp_rem)
+{
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+PrecInfo Async_Level_BlockILU0<scalar, index, bs, stor>::compute()
+{
+	const bool first = !op;
+	PrecInfo info = AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::compute();
+	if (first)  // src/solverops_levels_ilu0.cpp:48-55
+		HipOperator::check(blasted_hip_level_schedule(op->get()));
+	return info;
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Async_Level_BlockILU0<scalar, index, bs, stor>::apply(const scalar *const r,
+                                                           scalar *const __restrict z) const
+{
+	if (!op)
+		throw std::runtime_error("level ILU0: apply() before compute()");
+	// exact solves do not read an initial guess: the init type of the C ABI is irrelevant here
+	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
+	                                          BLASTED_HIP_HOST));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Async_Level_BlockILU0<scalar, index, bs, stor>::apply_device(const scalar *const dr,
+                                                                  scalar *const dz) const
+{
+	if (!op)
+		throw std::runtime_error("level ILU0: apply() before compute()");
+	HipOperator::check(blasted_hip_ilu0_apply(op->get(), dr, dz, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
+	                                          BLASTED_HIP_DEVICE));
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Async_Level_BlockILU0<scalar, index, bs, stor>::apply_relax(const scalar *const,
+                                                                 scalar *const __restrict) const
+{
+	throw std::runtime_error("ILU relaxation not implemented!");
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+int Async_Level_BlockILU0<scalar, index, bs, stor>::numLevels() const
+{
+	if (!op)
+		throw std::runtime_error("level ILU0: numLevels() before compute()");
+	int n = 0;
+	HipOperator::check(blasted_hip_level_count(op->get(), &n));
+	return n;
+}
+
 // ------------------------------------------------------------------------------- instantiations
 // the reference builds bs = 4, 5 (column-major), 4 (row-major) plus BUILD_BLOCK_SIZE
 // (src/solverops_ilu0.cpp:385-395); the device kernels cover 1, 2, 3, 4, 5, 7, 8 in both layouts.
@@ -405,7 +511,9 @@ void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const
 	template class BJacobiSRPreconditioner<double, int, BS, STOR>;         \
 	template class AsyncBlockSGS_SRPreconditioner<double, int, BS, STOR>;  \
 	template class ChaoticBlockRelaxation<double, int, BS, STOR>;          \
-	template class AsyncBlockILU0_SRPreconditioner<double, int, BS, STOR>;
+	template class AsyncBlockILU0_SRPreconditioner<double, int, BS, STOR>; \
+	template class Level_BSGS<double, int, BS, STOR>;                      \
+	template class Async_Level_BlockILU0<double, int, BS, STOR>;
 
 BLASTED_INSTANTIATE(1, ColMajor)
 BLASTED_INSTANTIATE(2, ColMajor)
@@ -425,5 +533,7 @@ template class JacobiSRPreconditioner<double, int>;
 template class AsyncSGS_SRPreconditioner<double, int>;
 template class ChaoticRelaxation<double, int>;
 template class AsyncILU0_SRPreconditioner<double, int>;
+template class Level_SGS<double, int>;
+template class Async_Level_ILU0<double, int>;
 
 }  // namespace blasted

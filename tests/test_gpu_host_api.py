@@ -29,6 +29,12 @@ CASES = [
     ("BSR4SeqILU0Colmajor", "2dcyl1", ["--preconditioner_type", "seqilu0", "--mat_type", "bsr"], 1e-10, 1e-8, 200),
     ("BSR4SapILU0Colmajor", "2dcyl1", ["--preconditioner_type", "sapilu0", "--mat_type", "bsr", "--build_sweeps", "12"], 1e-10, 1e-8, 200),
     ("BSR4RichardsonGS", "2dcyl1", ["--solver_type", "richardson", "--preconditioner_type", "gs", "--mat_type", "bsr", "--apply_sweeps", "10"], 1e-8, 1e-5, 2000),
+    ("BSR4LevelSGSColmajor", "2dcyl1", ["--preconditioner_type", "level_sgs", "--mat_type", "bsr"], 1e-10, 1e-8, 200),
+    ("CSRLevelSGS", "msc00726", ["--preconditioner_type", "level_sgs", "--mat_type", "csr"], 1e-10, 1e-10, 200),
+    ("BSR4AsyncLevelILU0Colmajor", "2dcyl1", ["--preconditioner_type", "async_level_ilu0", "--mat_type", "bsr", "--build_sweeps", "10"], 1e-10, 1e-8, 200),
+    ("BSR4AsyncLevelILU0Rowmajor", "2dcyl1", ["--preconditioner_type", "async_level_ilu0", "--mat_type", "bsr", "--storage_order", "rowmajor", "--build_sweeps", "10"], 1e-10, 1e-8, 200),
+    ("CSRAsyncLevelILU0", "2dcyl1", ["--preconditioner_type", "async_level_ilu0", "--mat_type", "csr", "--build_sweeps", "30"], 1e-10, 1e-8, 200),
+    ("BSR4RichardsonLevelSGS", "2dcyl1", ["--solver_type", "richardson", "--preconditioner_type", "level_sgs", "--mat_type", "bsr"], 1e-8, 1e-5, 2000),
     ("BSR4RichardsonSGS", "2dcyl1", ["--solver_type", "richardson", "--preconditioner_type", "sgs", "--mat_type", "bsr", "--apply_sweeps", "15"], 1e-8, 1e-5, 2000),
 ]
 
@@ -47,7 +53,7 @@ def test_native_solve(name, mat, extra, tol, testtol, maxiter):
 
 
 def test_factory_rejects_out_of_scope_types():
-    args = [DRIVER, "--preconditioner_type", "level_sgs", "--mat_type", "bsr",
+    args = [DRIVER, "--preconditioner_type", "cscbgs", "--mat_type", "csr",
             "--mat_file", os.path.join(G, "2dcyl1.mtx"), "--b_file", os.path.join(G, "2dcyl1_b.mtx")]
     r = subprocess.run(args, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and "outside the MI355X backend" in r.stderr
