@@ -127,6 +127,31 @@ def test_config2_async_factor_and_apply_properties(poisson256):
     assert ea <= es * 1.0001
 
 
+def test_config2_level_scheduled_apply_is_exact(poisson256):
+    """LEVEL mode at full size: 766 wavefront levels (i+j+k), and the result satisfies both triangular
+    systems -- checked with the torch evaluation of L y and U z."""
+    import torch
+    m, r, p = poisson256
+    assert p.level_count() == 3 * 256 - 2
+    lv, rows, ptr = p.get_levels()
+    i = np.arange(m["nbrows"])
+    assert np.array_equal(lv, (i % 256 + (i // 256) % 256 + i // 65536).astype(np.int32))
+    p.ilu0_factorize(3, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+    z = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+    nb = m["nbrows"]
+    F = torch.from_numpy(p.get_iluvals()).to(r.device)   # factor, diagonal blocks inverted
+    y = torch.from_numpy(p.get_ytemp()).to(r.device)
+    assert relmax(y, r - torch_part_matvec(m, F, y, "lower")) < 1e-12
+    dinv = F.view(-1, 4, 4)[m["diagind"].to(torch.int64)].transpose(1, 2)   # math layout [r][c]
+    t = y - torch_part_matvec(m, F, z, "upper")
+    assert relmax(z, torch.einsum("brc,bc->br", dinv, t.view(nb, 4)).reshape(-1)) < 1e-12
+    del F
+    # the async iteration converges to it
+    zlong = p.ilu0_apply(r, 60, mode=capi.ASYNC)
+    z3 = p.ilu0_apply(r, 3, mode=capi.ASYNC)
+    assert float((zlong - z).abs().max()) < float((z3 - z).abs().max())
+
+
 def test_config3_sgs_relaxation_matches_torch(poisson256):
     import torch
     m, r, p = poisson256
