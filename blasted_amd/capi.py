@@ -27,7 +27,7 @@ SYMBOLS = [
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
     "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
-    "blasted_hip_get_levels",
+    "blasted_hip_get_levels", "blasted_hip_level_stats",
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def lib():
         _lib.blasted_hip_level_schedule.argtypes = [vp]
         _lib.blasted_hip_level_count.argtypes = [vp, C.POINTER(ci)]
         _lib.blasted_hip_get_levels.argtypes = [vp, vp, vp, vp]
+        _lib.blasted_hip_level_stats.argtypes = [vp, vp]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
         for nm in ("iluvals", "dblocks", "scale", "ytemp"):
@@ -238,6 +239,12 @@ class Prec:
         n = C.c_int(0)
         _check(lib().blasted_hip_level_count(self._h, C.byref(n)))
         return n.value
+
+    def level_stats(self):
+        """-> dict(levels, build_passes, syncfree_passes, syncfree_aborts)"""
+        out = (C.c_long * 4)()
+        _check(lib().blasted_hip_level_stats(self._h, C.cast(out, C.c_void_p)))
+        return dict(zip(("levels", "build_passes", "syncfree_passes", "syncfree_aborts"), [int(v) for v in out]))
 
     def get_levels(self):
         """-> (level_of_row[nbrows], rows_by_level[nbrows], level_ptr[nlevels+1]) int32 numpy arrays."""

@@ -165,11 +165,47 @@ static void check_mode(int mode)
 		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC, BLASTED_HIP_JACOBI_SYNC or BLASTED_HIP_LEVEL");
 }
 
-static const LevelSchedule &need_levels(blasted_hip_prec p)
+static LevelSchedule &need_levels(blasted_hip_prec p)
 {
 	if (!p->levels.built)
 		build_level_schedule(p->pat, p->levels, p->stream);
 	return p->levels;
+}
+
+// 0: single persistent launch per exact pass, per-level launches as the fallback; 1: per-level launches
+static int g_level_impl = [] {
+	const char *e = std::getenv("BLASTED_HIP_LEVEL");
+	return (e && std::strcmp(e, "launch") == 0) ? 1 : 0;
+}();
+
+// One exact in-order pass of an operator producing `x` (for relaxation: from the previous iterate
+// `xold`, a different vector; otherwise xold is ignored).  Returns the number of launches.
+static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSrc dsrc, double *x,
+                      const double *xold)
+{
+	LevelSchedule &ls = need_levels(p);
+	a.changed = nullptr;
+	if (g_level_impl == 0) {
+		launch_syncfree_fill(x, p->n(), p->stream);
+		a.xin = xold ? xold : x;
+		a.xout = x;
+		if (launch_syncfree_sweep(a, part, post, dsrc, ls, p->stream)) {
+			// the pass is only valid if no wave gave up waiting: look at the abort flag before going on
+			int ctl[2] = {0, 0};
+			BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, p->stream));
+			BHIP_CHECK(hipStreamSynchronize(p->stream));
+			ls.sf_launches++;
+			if (!ctl[1])
+				return 2;
+			ls.sf_aborts++;
+		}
+	}
+	// per-level launches, in place: a relaxation pass starts from the previous iterate
+	if (xold && xold != x)
+		BHIP_CHECK(hipMemcpyAsync(x, xold, sizeof(double) * (size_t)p->n(), hipMemcpyDeviceToDevice, p->stream));
+	a.xin = x;
+	a.xout = x;
+	return launch_level_sweep(a, part, post, dsrc, ls, p->stream);
 }
 
 static SweepArgs base_args(blasted_hip_prec p)
@@ -190,20 +226,15 @@ static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post,
 {
 	Phase ph(p, kind);
 	if (nsweeps < 0 || mode == BLASTED_HIP_LEVEL) {
-		// exact in-order passes (sequential variants and the level-scheduled types): one launch per
-		// dependency level, in place.  A triangular pass reads only rows it has already written, so the
-		// initial content of x is never used and repeating it changes nothing: one pass is enough.
+		// exact in-order passes (sequential variants and the level-scheduled types), kernels_level.hip.
+		// A triangular pass reads only rows it has already written, so the initial content of x is never
+		// used and repeating the pass changes nothing: one pass is enough.
 		const bool triangular = part == PART_LOWER || part == PART_UPPER;
-		const int passes = nsweeps < 0 ? 1 : (triangular && nsweeps > 1 ? 1 : nsweeps);
-		const LevelSchedule &ls = need_levels(p);
-		if (!triangular && first_in && first_in != x && passes > 0)
-			BHIP_CHECK(hipMemcpyAsync(x, first_in, sizeof(double) * (size_t)p->n(), hipMemcpyDeviceToDevice,
-			                          p->stream));
-		a.xin = x;
-		a.xout = x;
-		a.changed = nullptr;
+		if (!triangular)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "run_sweeps: exact passes of this operator go through relax_impl");
+		const int passes = nsweeps < 0 ? 1 : (nsweeps > 1 ? 1 : nsweeps);
 		for (int s = 0; s < passes; s++)
-			ph.launches += launch_level_sweep(a, part, post, dsrc, ls, p->stream);
+			ph.launches += exact_pass(p, a, part, post, dsrc, x, nullptr);
 		ph.done();
 		return x;
 	}
@@ -828,7 +859,7 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 		a.vals = p->vals;
 		a.dvals = p->dblocks;
 		a.rhs = db;
-		double *other = (mode == BLASTED_HIP_JACOBI_SYNC) ? ensure(p->tmp[0], n) : nullptr;
+		double *other = (mode != BLASTED_HIP_ASYNC) ? ensure(p->tmp[0], n) : nullptr;
 		double *cur = dx;
 		for (int step = 0; step < maxits; step++) {
 			for (int dir = 0; dir < (symmetric ? 2 : 1); dir++) {
@@ -837,10 +868,10 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 				Phase ph(p, dir);
 				a.xin = cur;
 				a.xout = o;
-				if (mode == BLASTED_HIP_LEVEL)  // exact ascending / descending Gauss-Seidel pass
-					ph.launches = launch_level_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, need_levels(p),
-					                                 p->stream);
-				else {
+				if (mode == BLASTED_HIP_LEVEL) {  // exact ascending / descending Gauss-Seidel pass
+					o = (cur == dx) ? other : dx;
+					ph.launches = exact_pass(p, a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, o, cur);
+				} else {
 					launch_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, p->stream);
 					ph.launches = 1;
 				}
@@ -885,6 +916,21 @@ int blasted_hip_level_count(blasted_hip_prec p, int *nlevels)
 		if (!nlevels)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "level_count: null output");
 		*nlevels = need_levels(p).nlevels;
+	});
+}
+
+int blasted_hip_level_stats(blasted_hip_prec p, long *out4)
+{
+	return guarded([&] {
+		use_device(p);
+		need_pattern(p);
+		if (!out4)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "level_stats: null output");
+		const LevelSchedule &ls = need_levels(p);
+		out4[0] = ls.nlevels;
+		out4[1] = ls.build_passes;
+		out4[2] = ls.sf_launches;
+		out4[3] = ls.sf_aborts;
 	});
 }
 
@@ -1024,7 +1070,9 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 int blasted_hip_set_tuning(const char *spec)
 {
 	return guarded([&] {
-		if (spec && std::strncmp(spec, "factor4=", 8) == 0)
+		if (spec && std::strncmp(spec, "level=", 6) == 0)
+			g_level_impl = std::strcmp(spec + 6, "launch") == 0 ? 1 : 0;
+		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)
 			set_factor8_enabled(spec[8] != '0');

@@ -78,6 +78,13 @@ struct LevelSchedule {
 	int *rows = nullptr;   // device, nbrows: rows ordered by (level, row)
 	int *level = nullptr;  // device, nbrows: level of each row
 	std::vector<int> ptr;  // host, nlevels + 1: level l = rows[ptr[l] .. ptr[l+1])
+	// single-launch (sync-free) passes
+	int count = 0;                     // nbrows
+	int4 *meta = nullptr;              // device, nbrows: {row, browptr[row], diagind[row], browptr[row+1]} in level order
+	int *ctl = nullptr;                // device, 4 ints: claim counter, abort flag, (build: longest lower / upper part)
+	int max_lower = 0, max_upper = 0;  // longest strictly-lower / strictly-upper row part
+	int sf_grid = 1024;                // workgroups of a persistent launch
+	long sf_launches = 0, sf_aborts = 0;
 };
 
 struct FactorArgs {
@@ -103,6 +110,9 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void free_level_schedule(LevelSchedule &ls);
 int launch_level_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
                        hipStream_t s);
+void launch_syncfree_fill(double *x, long n, hipStream_t s);
+bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
+                           hipStream_t s);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);

@@ -14,7 +14,23 @@
 // pass and descending levels for a descending one, therefore reproduces the serial pass exactly: each
 // row is computed by the same expression from the final values of the rows it depends on.
 // On a matrix whose rows are renumbered level by level, the reference's computeLevels returns exactly
-// these level boundaries (tests/test_gpu_parity.py::test_level_schedule_matches_reference_levels).
+// these level boundaries (tests/test_gpu_levels.py::test_level_schedule_bit_exact).
+//
+// Two ways to run a pass:
+//  * launch_level_sweep: one launch per level (kernel boundaries order the levels);
+//  * launch_syncfree_sweep: ONE launch per pass.  Workgroup b owns positions [b*C, (b+1)*C) of the
+//    level-ordered row list; its waves request their rows' blocks and indices -- none of which depends
+//    on other rows -- and then poll the iterate entries they depend on until those stop being the
+//    "pending" bit pattern the output vector was filled with.  A row only ever waits for rows at
+//    earlier positions, i.e. for workgroups with a smaller id.  Each XCD starts its workgroups in
+//    increasing id order, so the unfinished workgroup with the smallest id is always resident and never
+//    waits: forward progress by induction (the same in-order-dispatch property rocSPARSE's csrsv relies
+//    on).
+//    Iterate entries are published and polled with relaxed agent-scope atomics (coherent across the
+//    8 XCD L2s); the 8-byte value is its own ready flag, so no fence is needed.  Spins are bounded: a
+//    wave that runs out sets an abort flag, every wave leaves, and the caller falls back to per-level
+//    launches.  Levels overlap and the matrix stream is prefetched while waiting, so the pass costs
+//    about one sweep's traffic plus (number of levels) x (one L2 round trip) of critical path.
 //
 // Build (once per pattern, all in HBM): chaotic fixed-point iteration of the definition above with
 // atomicMax (pull from the lower neighbours, push to the upper ones, so a structurally non-symmetric
@@ -210,6 +226,246 @@ void level_dispatch_layout(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
 		level_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s);
 }
 
+// meta[pos] = {row, browptr[row], diagind[row], browptr[row+1]} in level order; lens[0..1] = longest
+// strictly-lower / strictly-upper part of any row
+__global__ __launch_bounds__(256) void level_meta_kernel(const Pattern pat, const int *rows, int4 *meta,
+                                                         int *lens)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= pat.nbrows)
+		return;
+	const int row = rows[k];
+	const int rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
+	meta[k] = make_int4(row, rp0, dg, rp1);
+	atomicMax(lens, dg - rp0);
+	atomicMax(lens + 1, rp1 - dg - 1);
+}
+
+constexpr unsigned long long SF_PENDING = 0xFFF8DEADBEEF0001ull;  // a NaN payload arithmetic never produces
+constexpr int SF_SPIN_LIMIT = 1 << 22;
+
+__global__ __launch_bounds__(256) void sf_fill_kernel(unsigned long long *x, long n)
+{
+	const long i = (long)blockIdx.x * 256 + threadIdx.x;
+	if (i < n)
+		x[i] = SF_PENDING;
+}
+
+__device__ __forceinline__ double sf_load(const double *p)
+{
+	const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+	                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return __longlong_as_double((long long)v);
+}
+
+__device__ __forceinline__ void sf_store(double *p, double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool sf_pending(double v)
+{
+	return (unsigned long long)__double_as_longlong(v) == SF_PENDING;
+}
+
+// One exact pass as a single launch (see the file comment).  a.xout: the iterate being produced,
+// pre-filled with SF_PENDING; a.xin: the previous iterate, read for the stored blocks that are not
+// dependencies of the pass direction (relaxation only).  ctl[1] = abort flag.
+// A wave owns ST consecutive steps of RPW positions of the level-ordered row list (a workgroup 4 * ST
+// * RPW consecutive positions, workgroups in grid order).  Every block, index and right-hand side of
+// all ST steps is requested before the first wait; then the wave polls what is still pending, step by
+// step, and commits a row as soon as its group of lanes has everything.
+// KF = block passes held in registers: every row part must fit KF * NB blocks (checked by the launcher).
+template <int BS, bool RM, int PART, int POST, int DSRC, int KF, int ST>
+__global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const int4 *__restrict__ meta,
+                                                       const int count, int *ctl)
+{
+	using Ge = Geo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
+	constexpr int RPW = Ge::RPW;
+	constexpr bool DIAG_RIDES = PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG);
+	constexpr unsigned long long GMASK = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / G, t = lane % G;
+	const int slot = t / SUB, u = t % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(G - 1);
+	const bool desc = a.descending != 0;
+	const long base = ((long)blockIdx.x * 4 + wave) * (ST * RPW);
+
+	int4 mt[ST];
+	bool okk[ST];
+#pragma unroll
+	for (int st = 0; st < ST; st++) {
+		const long pos = base + st * RPW + g;
+		okk[st] = pos < count;
+		mt[st] = make_int4(0, 0, 0, 0);
+		if (okk[st])
+			mt[st] = meta[desc ? count - 1 - pos : pos];
+	}
+	// the rows' blocks and indices: independent of every other row, all in flight before any wait
+	double bv[ST][KF], xv[ST][KF], d[ST], rv[ST];
+	int xo[ST][KF];
+	unsigned dep[ST];
+#pragma unroll
+	for (int st = 0; st < ST; st++) {
+		const int row = mt[st].x, rp0 = mt[st].y, dg = mt[st].z, rp1 = mt[st].w;
+		int jbeg = 0, jend = 0;
+		if (okk[st]) {
+			if (PART == PART_LOWER) {
+				jbeg = rp0;
+				jend = dg;
+			} else if (PART == PART_UPPER) {
+				jbeg = DIAG_RIDES ? dg : dg + 1;
+				jend = rp1;
+			} else {
+				jbeg = rp0;
+				jend = rp1;
+			}
+		}
+		d[st] = 0.0;
+		dep[st] = 0u;
+#pragma unroll
+		for (int k = 0; k < KF; k++) {
+			const int jj = jbeg + slot + k * NB;
+			bv[st][k] = 0.0;
+			xv[st][k] = 0.0;
+			xo[st][k] = 0;
+			if (active && jj < jend && !(PART == PART_OFFDIAG && jj == dg)) {
+				const double v = a.vals[(long)jj * BS2 + e];
+				if (DIAG_RIDES && jj == dg) {
+					d[st] = (DSRC == D_VALS_DIAG) ? v : 1.0 / v;
+				} else {
+					const int col = a.pat.bcolind[jj];
+					bv[st][k] = v;
+					xo[st][k] = col * BS + c;
+					if (PART == PART_OFFDIAG && (desc ? col < row : col > row))
+						xv[st][k] = a.xin[xo[st][k]];  // not a dependency of this direction: previous iterate
+					else
+						dep[st] |= 1u << k;
+				}
+			}
+		}
+		if (DSRC == D_DBLOCKS && okk[st] && active && slot == 0)
+			d[st] = a.dvals[(long)row * BS2 + e];
+		rv[st] = 0.0;
+		if (okk[st] && r < BS && a.rhs) {
+			rv[st] = a.rhs[(long)row * BS + r];
+			if (a.rscale)
+				rv[st] *= a.rscale[(long)row * BS + r];
+		}
+	}
+
+	bool done[ST];
+#pragma unroll
+	for (int st = 0; st < ST; st++)
+		done[st] = !okk[st];
+	int spins = 0;
+	for (;;) {
+		bool alldone = true;
+#pragma unroll
+		for (int st = 0; st < ST; st++) {
+			if (__builtin_amdgcn_ballot_w64(!done[st]) == 0ull)
+				continue;  // wave-uniform: this step is finished
+#pragma unroll
+			for (int k = 0; k < KF; k++) {
+				if (dep[st] & (1u << k)) {
+					const double v = sf_load(a.xout + xo[st][k]);
+					if (!sf_pending(v)) {
+						xv[st][k] = v;
+						dep[st] &= ~(1u << k);
+					}
+				}
+			}
+			const unsigned long long rb = __builtin_amdgcn_ballot_w64(dep[st] == 0u);
+			const bool gready = ((rb >> gbase) & GMASK) == GMASK;
+			if (__builtin_amdgcn_ballot_w64(gready && !done[st]) != 0ull) {  // wave-uniform: something to commit
+				double acc = 0.0;
+#pragma unroll
+				for (int k = 0; k < KF; k++)
+					acc += bv[st][k] * (gready ? xv[st][k] : 0.0);
+				acc = allreduce_bits<Ge::LOBIT, Ge::HIBIT>(acc);
+				double out;
+				if (POST == POST_SUB) {
+					out = rv[st] - acc;
+				} else {
+					const double w = (POST == POST_D_SUB) ? rv[st] - acc : acc;
+					const double wc = __shfl(w, gbase + c, 64);
+					const double pr =
+					    allreduce_bits<Ge::LOBIT, Ge::HIBIT>((active && slot == 0) ? d[st] * wc : 0.0);
+					out = (POST == POST_D_SUB) ? pr : rv[st] - pr;
+				}
+				if (!done[st] && gready && slot == 0 && c == 0 && r < BS)
+					sf_store(a.xout + (long)mt[st].x * BS + r, out);
+				done[st] = done[st] || gready;
+			}
+			if (!done[st])
+				alldone = false;
+		}
+		if (__builtin_amdgcn_ballot_w64(!alldone) == 0ull)
+			return;
+		spins++;
+		if (spins > SF_SPIN_LIMIT ||
+		    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+
+template <int BS, bool RM, int PART, int POST, int DSRC>
+bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStream_t s)
+{
+	constexpr int NB = Geo<BS>::NB, RPW = Geo<BS>::RPW;
+	const int passes = (need + NB - 1) / NB;
+#define BHIP_KF(K, STEPS)                                                                                   \
+	if (passes <= K) {                                                                                      \
+		const long per_wg = 4L * STEPS * RPW;                                                               \
+		const long grid = ((long)ls.count + per_wg - 1) / per_wg;                                           \
+		if (grid > 0)                                                                                       \
+			hipLaunchKernelGGL((sf_sweep_kernel<BS, RM, PART, POST, DSRC, K, STEPS>), dim3((unsigned)grid), \
+			                   dim3(256), 0, s, a, ls.meta, ls.count, ls.ctl);                              \
+		return true;                                                                                        \
+	}
+	BHIP_KF(4, 4)
+	BHIP_KF(8, 2)
+	BHIP_KF(16, 1)
+#undef BHIP_KF
+	return false;
+}
+
+template <int BS, bool RM>
+bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls, hipStream_t s)
+{
+	const int lo = ls.max_lower, up = ls.max_upper;
+#define BHIP_CASE(P, Q, D, NEED)                                       \
+	if (part == P && post == Q && dsrc == D)                           \
+		return sf_launch_kf<BS, RM, P, Q, D>(a, ls, NEED, s);
+	BHIP_CASE(PART_LOWER, POST_SUB, D_NONE, lo)
+	BHIP_CASE(PART_UPPER, POST_D_SUB, D_VALS_DIAG, up + 1)
+	BHIP_CASE(PART_UPPER, POST_D_SUB, D_RECIP_DIAG, up + 1)
+	BHIP_CASE(PART_LOWER, POST_D_SUB, D_DBLOCKS, lo)
+	BHIP_CASE(PART_UPPER, POST_SUB_D, D_DBLOCKS, up)
+	BHIP_CASE(PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, lo + up + 1)
+#undef BHIP_CASE
+	BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_syncfree_sweep: operator combination not instantiated");
+}
+
+template <int BS>
+bool sf_dispatch_layout(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
+                        hipStream_t s)
+{
+	if (BS > 1 && a.pat.rowmajor)
+		return sf_dispatch_ops<BS, true>(a, part, post, dsrc, ls, s);
+	return sf_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s);
+}
+
 template <typename T>
 T *lvl_alloc(size_t count)
 {
@@ -226,6 +482,10 @@ void free_level_schedule(LevelSchedule &ls)
 		(void)hipFree(ls.rows);
 	if (ls.level)
 		(void)hipFree(ls.level);
+	if (ls.meta)
+		(void)hipFree(ls.meta);
+	if (ls.ctl)
+		(void)hipFree(ls.ctl);
 	ls = LevelSchedule();
 }
 
@@ -287,6 +547,21 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		for (int l = 0; l <= nlevels; l++)
 			if (ls.ptr[l] < 0 || (l > 0 && ls.ptr[l] <= ls.ptr[l - 1]))
 				BHIP_FAIL(BLASTED_HIP_ERUNTIME, "level schedule: empty level (internal error)");
+		// per-position row descriptors and the longest row parts (single-launch passes)
+		ls.meta = lvl_alloc<int4>(n);
+		ls.ctl = lvl_alloc<int>(4);
+		BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 4 * sizeof(int), s));
+		hipLaunchKernelGGL(level_meta_kernel, dim3(grid), dim3(256), 0, s, pat, rows, ls.meta, ls.ctl + 2);
+		int lens[2] = {0, 0};
+		BHIP_CHECK(hipMemcpyAsync(lens, ls.ctl + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+		ls.max_lower = lens[0];
+		ls.max_upper = lens[1];
+		int dev = 0, cus = 256;
+		BHIP_CHECK(hipGetDevice(&dev));
+		BHIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+		ls.sf_grid = cus * 4;
+		ls.count = n;
 		ls.nlevels = nlevels;
 		ls.rows = rows;
 		ls.level = level;
@@ -294,6 +569,12 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		level = nullptr;
 		ls.built = true;
 	} catch (...) {
+		if (ls.meta)
+			(void)hipFree(ls.meta);
+		if (ls.ctl)
+			(void)hipFree(ls.ctl);
+		ls.meta = nullptr;
+		ls.ctl = nullptr;
 		for (void *q : {(void *)level, (void *)keys, (void *)iota, (void *)rows, (void *)flags, (void *)dptr, tmp})
 			if (q)
 				(void)hipFree(q);
@@ -325,6 +606,42 @@ int launch_level_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, cons
 	}
 	BHIP_CHECK(hipGetLastError());
 	return ls.nlevels;
+}
+
+// Fills x (the iterate a single-launch pass will produce) with the "pending" pattern.
+void launch_syncfree_fill(double *x, long n, hipStream_t s)
+{
+	if (n <= 0)
+		return;
+	hipLaunchKernelGGL(sf_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+	                   reinterpret_cast<unsigned long long *>(x), n);
+}
+
+// One exact in-order pass as ONE persistent launch.  a.xout must have been filled by
+// launch_syncfree_fill; a.xin (relaxation: the previous iterate) must be a different, complete vector.
+// Returns false when a row part is too long for the register-held passes (caller uses
+// launch_level_sweep).  The abort flag ls.ctl[1] must be checked by the caller after the stream drains.
+bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
+                           hipStream_t s)
+{
+	if (!ls.built)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_syncfree_sweep: no level schedule");
+	if (part == PART_OFFDIAG && a.xin == a.xout)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_syncfree_sweep: relaxation passes need a second vector");
+	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+	bool ok = false;
+	switch (a.pat.bs) {
+	case 1: ok = sf_dispatch_layout<1>(a, part, post, dsrc, ls, s); break;
+	case 2: ok = sf_dispatch_layout<2>(a, part, post, dsrc, ls, s); break;
+	case 3: ok = sf_dispatch_layout<3>(a, part, post, dsrc, ls, s); break;
+	case 4: ok = sf_dispatch_layout<4>(a, part, post, dsrc, ls, s); break;
+	case 5: ok = sf_dispatch_layout<5>(a, part, post, dsrc, ls, s); break;
+	case 7: ok = sf_dispatch_layout<7>(a, part, post, dsrc, ls, s); break;
+	case 8: ok = sf_dispatch_layout<8>(a, part, post, dsrc, ls, s); break;
+	default: BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "block size not instantiated (1,2,3,4,5,7,8)");
+	}
+	BHIP_CHECK(hipGetLastError());
+	return ok;
 }
 
 }  // namespace bhip

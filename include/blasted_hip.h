@@ -136,6 +136,9 @@ int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsw
  * lazily by the first LEVEL-mode call; this entry point builds it eagerly (once per pattern). */
 int blasted_hip_level_schedule(blasted_hip_prec p);
 int blasted_hip_level_count(blasted_hip_prec p, int *nlevels);
+/* out4 = { levels, fixed-point passes of the build, single-launch exact passes run so far, how many of
+ * them gave up waiting and were redone with per-level launches (expected: 0) } */
+int blasted_hip_level_stats(blasted_hip_prec p, long *out4);
 /* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
  * inside a level), level_ptr[nlevels+1] */
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr);
@@ -167,7 +170,9 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 /* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
  * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>" for the tuned bs=4/8 kernel; the same strings
  * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
- * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4). */
+ * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
+ * "level=syncfree" (default) / "level=launch": exact passes as one persistent launch or as one launch
+ * per dependency level (environment: BLASTED_HIP_LEVEL). */
 int blasted_hip_set_tuning(const char *spec);
 
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */

@@ -23,6 +23,21 @@ CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16
          "random_bs4", "random_csr"]
 
 
+@pytest.fixture(params=["syncfree", "launch"], autouse=True)
+def level_impl(request):
+    """Every test runs with both implementations of an exact pass: one persistent launch that polls its
+    dependencies (default) and one launch per level."""
+    capi.set_tuning("level=" + request.param)
+    yield request.param
+    capi.set_tuning("level=syncfree")
+
+
+def check_stats(p, impl):
+    st = p.level_stats()
+    assert st["syncfree_aborts"] == 0
+    assert (st["syncfree_passes"] > 0) == (impl == "syncfree")
+
+
 def one_sided(m):
     """Drops the strictly-upper block of some coupled pairs: a structurally NON-symmetric pattern."""
     nb, bs2 = m["nbrows"], m["bs"] ** 2
@@ -81,7 +96,7 @@ def test_level_schedule_nonsymmetric_pattern(golden):
 
 @pytest.mark.parametrize("scaling", [False, True])
 @pytest.mark.parametrize("case", CASES)
-def test_level_ilu0_apply(golden, case, scaling):
+def test_level_ilu0_apply(golden, case, scaling, level_impl):
     """async_level_ilu0: asynchronous factorisation, exact (level-scheduled) triangular solves."""
     m = matrices(golden)[case]()
     n = m["nbrows"] * m["bs"]
@@ -98,6 +113,7 @@ def test_level_ilu0_apply(golden, case, scaling):
     # more sweeps or the sequential symbol change nothing: one pass is already exact
     assert np.array_equal(p.ilu0_apply(r, 3, mode=capi.LEVEL), z)
     assert np.array_equal(p.ilu0_apply(r, -1), z)
+    check_stats(p, level_impl)
     # the reference's level-scheduled operator on the level-ordered matrix, mapped back
     lv, rows, ptr = p.get_levels()
     try:
@@ -117,7 +133,7 @@ def test_level_ilu0_apply(golden, case, scaling):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_level_sgs(golden, case):
+def test_level_sgs(golden, case, level_impl):
     """level_sgs: exact symmetric Gauss-Seidel application and relaxation."""
     m = matrices(golden)[case]()
     n = m["nbrows"] * m["bs"]
@@ -138,6 +154,7 @@ def test_level_sgs(golden, case):
     wantg = O.gs_relax(m, gd, r, x0=x0, nsweeps=3, mode=O.GS_SERIAL)
     if np.all(np.isfinite(wantg)) and np.abs(wantg).max() < 1e6:
         assert rel(xg, wantg) < 1e-11
+    check_stats(p, level_impl)
     lv, rows, ptr = p.get_levels()
     mp = W.permute_symmetric(m, rows)
     perm = (rows[:, None].astype(np.int64) * bs + np.arange(bs)[None, :]).reshape(-1)
