@@ -526,6 +526,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.lowerp = p->lowerp;
 		fa.upperp = p->upperp;
 		fa.changed = nullptr;
+		fa.rows = nullptr;
+		fa.nrows = 0;
 		fa.dinv_scratch = nullptr;
 		if (pat.bs >= 5)
 			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * pat.bs * pat.bs);
@@ -543,33 +545,13 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		// async_bilu0_sweeps, src/async_blockilu_factor.cpp:186-204
 		double *cur = p->iluvals;
 		if (nbuildsweeps < 0) {
-			// sequential factorisation (seqilu0 / sfilu0): sweep in place until stationary, see run_sweeps
+			// sequential factorisation (seqilu0 / sfilu0): the exact ILU(0) of one in-order pass, run as
+			// one launch per dependency level (kernels_factor.hip: launch_factor_levels)
 			Phase ph(p, 0);
-			constexpr int BATCH = 8;
-			if (!p->flags)
-				p->flags = dev_alloc<int>(BATCH);
-			const long cap = (long)pat.nnzb + 2;
-			int hflags[BATCH];
-			bool stationary = false;
 			fa.in = p->iluvals;
 			fa.out = p->iluvals;
-			for (long done = 0; done < cap && !stationary; done += BATCH) {
-				BHIP_CHECK(hipMemsetAsync(p->flags, 0, sizeof(int) * BATCH, p->stream));
-				for (int s = 0; s < BATCH; s++) {
-					fa.changed = p->flags + s;
-					launch_factor_sweep(fa, p->stream);
-					ph.launches++;
-				}
-				BHIP_CHECK(hipMemcpyAsync(hflags, p->flags, sizeof(int) * BATCH, hipMemcpyDeviceToHost, p->stream));
-				BHIP_CHECK(hipStreamSynchronize(p->stream));
-				for (int s = 0; s < BATCH; s++)
-					if (!hflags[s])
-						stationary = true;
-			}
+			ph.launches = launch_factor_levels(fa, need_levels(p), p->stream);
 			ph.done();
-			fa.changed = nullptr;
-			if (!stationary)
-				BHIP_FAIL(BLASTED_HIP_ERUNTIME, "sequential factorisation did not become stationary");
 		} else {
 			Phase ph(p, 0);
 			for (int s = 0; s < nbuildsweeps; s++) {

@@ -96,6 +96,8 @@ struct FactorArgs {
 	double *out;            // factor values written (== in for async)
 	int *changed;           // optional flag, as in SweepArgs
 	double *dinv_scratch;   // optional nbrows*bs*bs scratch (bs=8 tuned path: inverted diagonal blocks)
+	const int *rows;        // optional row list (level-scheduled exact factorisation), else all rows
+	int nrows;              // length of `rows`
 };
 
 // kernels_sweep.hip
@@ -121,6 +123,7 @@ bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s);
 void set_factor8_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
+int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,
                                double *dst, long dst_is_indexed_by_diag, hipStream_t s);
 void launch_fact_init(const Pattern &pat, const double *avals, const double *scale, int init_type,

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 
 	const unsigned chunk = xcd_chunk_f(blockIdx.x, gridDim.x);
 	const long rowlin = (long)chunk * Ge::RPB + wave * Ge::RPW + g;
-	const bool rowok = rowlin < a.pat.nbrows;
-	const int irow = rowok ? (int)rowlin : 0;
+	const bool rowok = rowlin < (a.rows ? a.nrows : a.pat.nbrows);
+	const int irow = rowok ? (a.rows ? a.rows[rowlin] : (int)rowlin) : 0;
 	int jbeg = 0, jend = 0;
 	if (rowok) {
 		jbeg = a.pat.browptr[irow];
@@ -521,6 +521,32 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 		                   (double *)nullptr);
 	})
 	BHIP_CHECK(hipGetLastError());
+}
+
+// Exact ILU(0) in one pass (the reference's sequential factorisation, threadedfactor = false: one
+// in-order sweep, src/async_blockilu_factor.cpp:186-204 with one thread): one launch per dependency
+// level over that level's rows, in place.  A row's entries need final values of rows in earlier levels
+// only (its lower neighbours' upper parts and diagonals), and the group that owns a row walks its
+// entries in storage order, reading back what it has just stored -- exactly the serial recurrence.
+int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
+{
+	if (!ls.built)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_factor_levels: no level schedule");
+	if (a.in != a.out)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_factor_levels: in place only");
+	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels are inverted on the fly
+	a.changed = nullptr;
+	for (int l = 0; l < ls.nlevels; l++) {
+		a.rows = ls.rows + ls.ptr[l];
+		a.nrows = ls.ptr[l + 1] - ls.ptr[l];
+		BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
+			const unsigned grid = (unsigned)(((long)a.nrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+			hipLaunchKernelGGL((factor_sweep_kernel<BS, RM, false>), dim3(grid), dim3(256), 0, s, a,
+			                   (double *)nullptr);
+		})
+	}
+	BHIP_CHECK(hipGetLastError());
+	return ls.nlevels;
 }
 
 double run_nonlinear_res(const FactorArgs &a, double *dev_scratch, hipStream_t s)

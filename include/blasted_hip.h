@@ -102,8 +102,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
  * apply_init other than ZERO / JACOBI -> BLASTED_HIP_EINVAL (the reference throws, :125-126).
  * A negative sweep count (BLASTED_SEQUENTIAL_SYMBOL) selects the reference's sequential variants
  * (threadedfactor / threadedapply = false), i.e. the result of one in-order serial pass: apply runs one
- * level-scheduled pass (mode LEVEL); factorize repeats in-place sweeps until one changes nothing, which
- * is the serial result bit for bit. */
+ * level-scheduled pass (mode LEVEL); factorize runs the exact ILU(0) as one launch per dependency level,
+ * each row's entries computed in storage order from final values of the earlier levels. */
 int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,
                            int apply_init, int mode, int loc);
 

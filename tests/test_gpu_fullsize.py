@@ -152,6 +152,18 @@ def test_config2_level_scheduled_apply_is_exact(poisson256):
     assert float((zlong - z).abs().max()) < float((z3 - z).abs().max())
 
 
+def test_config2_exact_factorisation_has_no_remainder(poisson256):
+    """seqilu0's factorisation at full size (one launch per dependency level): A - LU vanishes on the
+    pattern, the reference's own criterion (tests/solverops/async_ilu_convergence.cpp:462-490,574-575)."""
+    m, r, p = poisson256
+    info = p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL, compute_info=True)
+    assert np.isfinite(info).all()
+    assert info[0] < 2e-15 * info[1]
+    # three asynchronous sweeps leave a remainder many orders above that
+    info3 = p.ilu0_factorize(3, init=capi.INIT_F_ORIGINAL, compute_info=True)
+    assert info3[0] > 1e3 * info[0]
+
+
 def test_config3_sgs_relaxation_matches_torch(poisson256):
     import torch
     m, r, p = poisson256
