@@ -104,6 +104,7 @@ struct FactorArgs {
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 bool sweep_supported(int bs);
 bool sweep_offsets_fit(const Pattern &pat);
+void set_sweep_unroll(int u);
 // kernels_sweepw.hip (tuned bs=4/8 column-major path; false = not covered, use the generic family)
 bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepw_variant(const char *spec);

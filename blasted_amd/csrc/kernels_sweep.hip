@@ -36,9 +36,10 @@
 
 namespace bhip {
 
-template <int BS, bool RM, int PART, int POST, int DSRC>
+template <int BS, bool RM, int PART, int POST, int DSRC, int UNR>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
+	static_assert((Geo<BS>::RCHUNK / Geo<BS>::RSTEP) % UNR == 0, "row steps per chunk must be a multiple of UNR");
 	using Ge = Geo<BS>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
 	constexpr int RPW = Ge::RPW, RSTEP = Ge::RSTEP, RCHUNK = Ge::RCHUNK, CAP = Ge::CAP;
@@ -98,106 +99,126 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * BS2);
 	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * BS);
 
-	for (int step = 0; step < RCHUNK / RSTEP; step++) {
-		const int ls = step * RSTEP + wave * RPW + g;  // position in sweep order
-		const bool ok = ls < rc;
-		const int lr = ok ? (a.descending ? rc - 1 - ls : ls) : 0;
-		const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1], dg = s_dg[lr];
-		int jbeg = 0, jend = 0;
-		if (ok) {
-			if (PART == PART_LOWER) {
-				jbeg = rp0;
-				jend = dg;
-			} else if (PART == PART_UPPER) {
-				// the diagonal item rides in front of the upper ones when D is the factor's own diagonal
-				jbeg = (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) ? dg : dg + 1;
-				jend = rp1;
-			} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
-				jbeg = rp0;
-				jend = rp1;
-			}
-		}
-
-		double bv[KFIX], xv[KFIX];
+	for (int step = 0; step < RCHUNK / RSTEP; step += UNR) {
+		// UNR row steps are issued together: all their loads are in flight before the first use
+		bool ok[UNR];
+		int lr[UNR], dg[UNR], jbeg[UNR], jend[UNR];
 #pragma unroll
-		for (int k = 0; k < KFIX; k++) {
-			const int jj = jbeg + slot + k * NB;
-			bv[k] = 0.0;
-			xv[k] = 0.0;
-			if (PART != PART_NONE && jj < jend && active) {
-				bv[k] = *reinterpret_cast<const double *>(
-				    vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
-				const bool isdiag = (jj == dg);
-				if (!((PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && isdiag) ||
-				      (PART == PART_OFFDIAG && isdiag))) {
-					const int cidx = jj - jlo;
-					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					xv[k] = *reinterpret_cast<const double *>(
-					    xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+		for (int q = 0; q < UNR; q++) {
+			const int ls = (step + q) * RSTEP + wave * RPW + g;  // position in sweep order
+			ok[q] = ls < rc;
+			lr[q] = ok[q] ? (a.descending ? rc - 1 - ls : ls) : 0;
+			const int rp0 = s_rp[lr[q]], rp1 = s_rp[lr[q] + 1];
+			dg[q] = s_dg[lr[q]];
+			jbeg[q] = 0;
+			jend[q] = 0;
+			if (ok[q]) {
+				if (PART == PART_LOWER) {
+					jbeg[q] = rp0;
+					jend[q] = dg[q];
+				} else if (PART == PART_UPPER) {
+					// the diagonal item rides in front of the upper ones when D is the factor's own diagonal
+					jbeg[q] = (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) ? dg[q] : dg[q] + 1;
+					jend[q] = rp1;
+				} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
+					jbeg[q] = rp0;
+					jend[q] = rp1;
 				}
 			}
 		}
-		double d = 0.0;
-		if (DSRC == D_DBLOCKS && ok && active && slot == 0)
-			d = *reinterpret_cast<const double *>(dbase + ((unsigned)lr * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
-		double rv = 0.0;
-		if (ok && r < BS && a.rhs) {
-			rv = *reinterpret_cast<const double *>(rbase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
-			if (a.rscale)
-				rv *= *reinterpret_cast<const double *>(sbase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
-		}
 
-		double acc = 0.0;
-		if (PART != PART_NONE) {
+		double bv[UNR][KFIX], xv[UNR][KFIX], d[UNR], rv[UNR];
+#pragma unroll
+		for (int q = 0; q < UNR; q++) {
 #pragma unroll
 			for (int k = 0; k < KFIX; k++) {
-				if (PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && k == 0) {
-					const bool isd = (slot == 0);  // item 0 of the row: its diagonal block / entry
-					if (DSRC == D_VALS_DIAG)
-						d = isd ? bv[0] : d;
-					else
-						d = (isd && ok) ? 1.0 / bv[0] : d;
-					acc += isd ? 0.0 : bv[0] * xv[0];
-				} else
-					acc += bv[k] * xv[k];  // xv is zero for skipped / absent items
-			}
-			for (int jj = jbeg + slot + KFIX * NB; jj < jend; jj += NB) {
-				if (PART == PART_OFFDIAG && jj == dg)
-					continue;
-				if (active) {
-					const int cidx = jj - jlo;
-					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					acc += *reinterpret_cast<const double *>(
-					           vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e)) *
-					       *reinterpret_cast<const double *>(
-					           xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+				const int jj = jbeg[q] + slot + k * NB;
+				bv[q][k] = 0.0;
+				xv[q][k] = 0.0;
+				if (PART != PART_NONE && jj < jend[q] && active) {
+					bv[q][k] = *reinterpret_cast<const double *>(
+					    vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+					const bool isdiag = (jj == dg[q]);
+					if (!((PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && isdiag) ||
+					      (PART == PART_OFFDIAG && isdiag))) {
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						xv[q][k] = *reinterpret_cast<const double *>(
+						    xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+					}
 				}
 			}
-			acc = allreduce_bits<Ge::LOBIT, Ge::HIBIT>(acc);  // lanes (r,*,*) now hold row r of the sum
+			d[q] = 0.0;
+			if (DSRC == D_DBLOCKS && ok[q] && active && slot == 0)
+				d[q] = *reinterpret_cast<const double *>(dbase + ((unsigned)lr[q] * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+			rv[q] = 0.0;
+			if (ok[q] && r < BS && a.rhs) {
+				rv[q] = *reinterpret_cast<const double *>(rbase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
+				if (a.rscale)
+					rv[q] *= *reinterpret_cast<const double *>(sbase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
+			}
 		}
 
-		double out;
-		if (POST == POST_SUB) {
-			out = rv - acc;
-		} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
-			const double w = (POST == POST_D_SUB) ? rv - acc : acc;
-			const double wc = __shfl(w, gbase + c, 64);  // lane (c,0) of block slot 0 holds component c
-			// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
-			const double p = allreduce_bits<Ge::LOBIT, Ge::HIBIT>((active && slot == 0) ? d * wc : 0.0);
-			out = (POST == POST_D_SUB) ? p : rv - p;
-		} else {
-			out = a.a * acc;
-			if (a.b != 0.0)
-				out += a.b * rv;
-		}
+#pragma unroll
+		for (int q = 0; q < UNR; q++) {
+			double acc = 0.0;
+			if (PART != PART_NONE) {
+#pragma unroll
+				for (int k = 0; k < KFIX; k++) {
+					if (PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG) && k == 0) {
+						const bool isd = (slot == 0);  // item 0 of the row: its diagonal block / entry
+						if (DSRC == D_VALS_DIAG)
+							d[q] = isd ? bv[q][0] : d[q];
+						else
+							d[q] = (isd && ok[q]) ? 1.0 / bv[q][0] : d[q];
+						acc += isd ? 0.0 : bv[q][0] * xv[q][0];
+					} else
+						acc += bv[q][k] * xv[q][k];  // xv is zero for skipped / absent items
+				}
+				for (int jj = jbeg[q] + slot + KFIX * NB; jj < jend[q]; jj += NB) {
+					if (PART == PART_OFFDIAG && jj == dg[q])
+						continue;
+					if (active) {
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						acc += *reinterpret_cast<const double *>(
+						           vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e)) *
+						       *reinterpret_cast<const double *>(
+						           xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+					}
+				}
+				acc = allreduce_bits<Ge::LOBIT, Ge::HIBIT>(acc);  // lanes (r,*,*) now hold row r of the sum
+			}
 
-		if (ok && slot == 0 && c == 0 && r < BS) {
-			double *const dst = reinterpret_cast<double *>(obase + ((unsigned)lr * (unsigned)(BS * 8) + 8u * (unsigned)r));
-			if (a.changed && !(*dst == out))
-				*a.changed = 1;
-			*dst = out;
+			double out;
+			if (POST == POST_SUB) {
+				out = rv[q] - acc;
+			} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
+				const double w = (POST == POST_D_SUB) ? rv[q] - acc : acc;
+				const double wc = __shfl(w, gbase + c, 64);  // lane (c,0) of block slot 0 holds component c
+				// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
+				const double p = allreduce_bits<Ge::LOBIT, Ge::HIBIT>((active && slot == 0) ? d[q] * wc : 0.0);
+				out = (POST == POST_D_SUB) ? p : rv[q] - p;
+			} else {
+				out = a.a * acc;
+				if (a.b != 0.0)
+					out += a.b * rv[q];
+			}
+
+			if (ok[q] && slot == 0 && c == 0 && r < BS) {
+				double *const dst = reinterpret_cast<double *>(obase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
+				if (a.changed && !(*dst == out))
+					*a.changed = 1;
+				*dst = out;
+			}
 		}
 	}
+}
+
+static int g_sweep_unroll = 0;  // 0 = default (2 where it applies), 1 = never unroll (measurements)
+void set_sweep_unroll(int u)
+{
+	g_sweep_unroll = u;
 }
 
 template <int BS, bool RM>
@@ -208,7 +229,12 @@ static void dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, hi
 		return;
 #define BHIP_CASE(P, Q, D)                                                                       \
 	if (part == P && post == Q && dsrc == D) {                                                   \
-		hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D>), dim3(grid), dim3(256), 0, s, a);     \
+		/* one block-row per wave (bs >= 5): two row steps in flight for the triangular sweeps */ \
+		constexpr int U = (Geo<BS>::G == 64 && (P == PART_LOWER || P == PART_UPPER)) ? 2 : 1;    \
+		if (g_sweep_unroll == 1)                                                                 \
+			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, 1>), dim3(grid), dim3(256), 0, s, a); \
+		else                                                                                     \
+			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, U>), dim3(grid), dim3(256), 0, s, a); \
 		return;                                                                                  \
 	}
 	BHIP_CASE(PART_LOWER, POST_SUB, D_NONE)
