@@ -1,0 +1,261 @@
+// kernels_sweep5.hip -- the tuned row-sweep kernel for column-major 5x5 blocks: the reference's other
+// stock block size (src/solverops_ilu0.cpp:385-395, the 3-D compressible-flow case its author targets)
+// and BASELINE.json's config 4.  Same operators and arithmetic as the generic family in
+// kernels_sweep.hip (table there); the generic kernel pads a 5x5 block to an 8x8 lane tile, so one
+// wave load instruction moves a single 200-byte block -- this kernel moves four:
+//
+//  * 16 lanes own one block-row, 13 of them one stored block per pass: lane q < 12 reads entries
+//    (2q, 2q+1) as 16 bytes, lane 12 reads (23, 24) and uses 24.  A block starts at a multiple of 200
+//    bytes, so half of these loads are 8- but not 16-byte aligned (gfx950 global loads take that);
+//  * the x segment is gathered as 16 bytes per lane too: the two entries of a lane lie in column c or
+//    in columns c, c+1 of the block, so (x_c, x_{c+1}) covers both (for c = 4: (x_3, x_4));
+//  * entry e = 5c + r contributes to component r, which follows no power-of-two lane pattern: the 25
+//    partial products of a row go through a 200-byte LDS tile and five lanes per row sum their
+//    component's column (wave-private tile: LDS executes a wave's instructions in order, no barrier);
+//    the diagonal-block product of the upper solve / Gauss-Seidel goes the same way;
+//  * row chunk, LDS-staged browptr / diagind / bcolind range, straight-line predicated block passes,
+//    32-bit chunk-relative offsets and XCD-contiguous chunk numbering as in kernels_sweepw.hip.
+#include "ctx.hpp"
+#include "lanes.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace bhip {
+
+namespace {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef d2_t d2u_t __attribute__((aligned(8)));  // 16-byte access at 8-byte alignment
+
+__device__ __forceinline__ d2_t load16u(const char *p)
+{
+	return *reinterpret_cast<const d2u_t *>(p);
+}
+
+__device__ __forceinline__ d2_t load16u_nt(const char *p)
+{
+	return __builtin_nontemporal_load(reinterpret_cast<const d2u_t *>(p));
+}
+
+template <int PART, int POST, int DSRC, int RCHUNK>
+__global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
+{
+	constexpr int BS = 5, BS2 = 25, RPW = 4, RSTEP = 16, CAP = 16 * RCHUNK;
+	constexpr int BLKBYTES = BS2 * 8, ROWBYTES = BS * 8;
+	constexpr int KFIX = (PART == PART_ALL || PART == PART_OFFDIAG) ? 8 : 4;
+	constexpr bool DIAG_RIDES = PART == PART_UPPER && DSRC == D_VALS_DIAG;
+	constexpr bool USES_D = POST == POST_D_SUB || POST == POST_SUB_D;
+
+	__shared__ int s_rp[RCHUNK + 1];
+	__shared__ int s_dg[RCHUNK];
+	__shared__ int s_col[CAP];
+	__shared__ double s_acc[4][RPW][26];  // [wave][row of the step][entry]
+	__shared__ double s_w[4][RPW][6];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int g = lane >> 4, t = lane & 15;
+	const bool actA = t < 12, actB = t < 13;
+	const int eA = actA ? 2 * t : 23, eB = actA ? 2 * t + 1 : 24;
+	const unsigned boff = actA ? 16u * (unsigned)t : 184u;  // lane 12: entries (23, 24)
+	const int cA = eA / 5, cB = eB / 5;
+	const int cx = cA < 3 ? cA : 3;  // gathered pair (x_cx, x_cx+1)
+	const bool hiA = cA != cx, hiB = cB != cx;
+
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const long lin0 = (long)chunk * RCHUNK;
+	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
+	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;
+
+	for (int k = tid; k <= rc; k += 256)
+		s_rp[k] = a.pat.browptr[r0 + k];
+	for (int k = tid; k < rc; k += 256)
+		s_dg[k] = a.pat.diagind[r0 + k];
+	__syncthreads();
+	int jlo, jhi;
+	if (PART == PART_LOWER) {
+		jlo = s_rp[0];
+		jhi = s_dg[rc - 1];
+	} else if (PART == PART_UPPER) {
+		jlo = s_dg[0];
+		jhi = s_rp[rc];
+	} else {
+		jlo = s_rp[0];
+		jhi = s_rp[rc];
+	}
+	jlo = __builtin_amdgcn_readfirstlane(jlo);
+	jhi = __builtin_amdgcn_readfirstlane(jhi);
+	if (PART != PART_NONE) {
+		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
+		for (int k = tid; k < ncol; k += 256)
+			s_col[k] = a.pat.bcolind[jlo + k];
+	}
+	__syncthreads();
+
+	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * BS2);
+	const char *const xbase = reinterpret_cast<const char *>(a.xin);
+	const char *const rbase = reinterpret_cast<const char *>(a.rhs + (long)r0 * BS);
+	const char *const sbase = reinterpret_cast<const char *>(a.rscale + (long)r0 * BS);
+	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * BS2);
+	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * BS);
+	double *const tile = &s_acc[wave][g][0];
+	double *const wvec = &s_w[wave][g][0];
+
+	for (int step = 0; step < RCHUNK / RSTEP; step++) {
+		const int ls = step * RSTEP + wave * RPW + g;  // position in sweep order
+		const bool ok = ls < rc;
+		const int lr = ok ? (a.descending ? rc - 1 - ls : ls) : 0;
+		const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1], dg = s_dg[lr];
+		int jbeg = 0, jend = 0;
+		if (ok) {
+			if (PART == PART_LOWER) {
+				jbeg = rp0;
+				jend = dg;
+			} else if (PART == PART_UPPER) {
+				jbeg = DIAG_RIDES ? dg : dg + 1;  // first item = the (inverted) diagonal block
+				jend = rp1;
+			} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
+				jbeg = rp0;
+				jend = rp1;
+			}
+		}
+
+		d2_t bv[KFIX], xv[KFIX];
+#pragma unroll
+		for (int k = 0; k < KFIX; k++) {
+			const int jj = jbeg + k;
+			bv[k].x = bv[k].y = 0.0;
+			xv[k].x = xv[k].y = 0.0;
+			if (PART != PART_NONE && jj < jend && actB) {
+				bv[k] = load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
+				const bool isdiag = (jj == dg);
+				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {
+					const int cidx = jj - jlo;
+					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					xv[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
+				}
+			}
+		}
+		d2_t dv;
+		dv.x = dv.y = 0.0;
+		if (DSRC == D_DBLOCKS && ok && actB)
+			dv = load16u(dbase + ((unsigned)lr * (unsigned)BLKBYTES + boff));
+		double rv = 0.0;
+		if (ok && t < BS && a.rhs) {
+			rv = *reinterpret_cast<const double *>(rbase + ((unsigned)lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
+			if (a.rscale)
+				rv *= *reinterpret_cast<const double *>(sbase + ((unsigned)lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
+		}
+
+		double sum = 0.0;  // component t of sum_j A_ij x_j, lanes t < 5
+		if (PART != PART_NONE) {
+			double accA = 0.0, accB = 0.0;
+#pragma unroll
+			for (int k = 0; k < KFIX; k++) {
+				if (DIAG_RIDES && k == 0) {
+					dv = bv[0];  // item 0 of the row is its diagonal block: xv[0] was not loaded (zero)
+				} else {
+					accA += bv[k].x * (hiA ? xv[k].y : xv[k].x);
+					accB += bv[k].y * (hiB ? xv[k].y : xv[k].x);
+				}
+			}
+			for (int jj = jbeg + KFIX; jj < jend; jj++) {
+				if (PART == PART_OFFDIAG && jj == dg)
+					continue;
+				if (actB) {
+					const d2_t v2 = load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
+					const int cidx = jj - jlo;
+					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					const d2_t x2 = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
+					accA += v2.x * (hiA ? x2.y : x2.x);
+					accB += v2.y * (hiB ? x2.y : x2.x);
+				}
+			}
+			// 25 partial products -> 5 components through the wave-private tile
+			if (actA)
+				tile[eA] = accA;
+			if (actB)
+				tile[eB] = accB;
+			__builtin_amdgcn_wave_barrier();
+			if (t < BS)
+				sum = tile[t] + tile[5 + t] + tile[10 + t] + tile[15 + t] + tile[20 + t];
+			__builtin_amdgcn_wave_barrier();
+		}
+
+		double out;
+		if (POST == POST_SUB) {
+			out = rv - sum;
+		} else if (USES_D) {
+			const double w = (POST == POST_D_SUB) ? rv - sum : sum;
+			if (t < BS)
+				wvec[t] = w;
+			__builtin_amdgcn_wave_barrier();
+			const double wA = wvec[cA], wB = wvec[cB];
+			if (actA)
+				tile[eA] = dv.x * wA;
+			if (actB)
+				tile[eB] = dv.y * wB;
+			__builtin_amdgcn_wave_barrier();
+			double pr = 0.0;
+			if (t < BS)
+				pr = tile[t] + tile[5 + t] + tile[10 + t] + tile[15 + t] + tile[20 + t];
+			__builtin_amdgcn_wave_barrier();
+			out = (POST == POST_D_SUB) ? pr : rv - pr;
+		} else {
+			out = a.a * sum;
+			if (a.b != 0.0)
+				out += a.b * rv;
+		}
+
+		if (ok && t < BS)
+			*reinterpret_cast<double *>(obase + ((unsigned)lr * (unsigned)ROWBYTES + 8u * (unsigned)t)) = out;
+	}
+}
+
+int g_sweep5_enabled = [] {
+	const char *e = std::getenv("BLASTED_HIP_SWEEP5");
+	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
+}();
+
+template <int PART, int POST, int DSRC>
+void launch5(const SweepArgs &a, hipStream_t s)
+{
+	constexpr int RCHUNK = 128;
+	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
+	hipLaunchKernelGGL((sweep5_kernel<PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+void set_sweep5_enabled(int on)
+{
+	g_sweep5_enabled = on;
+}
+
+// returns false when the tuned kernel does not cover the request (caller uses the generic family)
+bool launch_sweep5(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
+{
+	if (!g_sweep5_enabled || a.pat.bs != 5 || a.pat.rowmajor || a.pat.nbrows == 0 || a.changed)
+		return false;
+	bool ok = true;
+#define BHIP_CASE5(P, Q, D)                           \
+	if (part == P && post == Q && dsrc == D)          \
+		launch5<P, Q, D>(a, s);                       \
+	else
+	BHIP_CASE5(PART_LOWER, POST_SUB, D_NONE)
+	BHIP_CASE5(PART_UPPER, POST_D_SUB, D_VALS_DIAG)
+	BHIP_CASE5(PART_LOWER, POST_D_SUB, D_DBLOCKS)
+	BHIP_CASE5(PART_UPPER, POST_SUB_D, D_DBLOCKS)
+	BHIP_CASE5(PART_OFFDIAG, POST_D_SUB, D_DBLOCKS)
+	BHIP_CASE5(PART_ALL, POST_AXPBY, D_NONE)
+	BHIP_CASE5(PART_NONE, POST_D_SUB, D_DBLOCKS)
+	ok = false;
+#undef BHIP_CASE5
+	if (ok)
+		BHIP_CHECK(hipGetLastError());
+	return ok;
+}
+
+}  // namespace bhip

@@ -38,7 +38,7 @@ def main():
         nnzb, nb = m["nnzb"], m["nbrows"]
         pair_bytes = (nnzb * (8 * bs * bs + 4)) + 4 * nb * 4 + 6 * nb * 8 * bs
         for rep in range(2):
-            for spec in ("gunroll=1", "gunroll=0"):
+            for spec in ("sweep5=0", "sweep5=1"):
                 capi.set_tuning(spec)
                 t = timed(lambda: p.ilu0_apply(r, 3, out=z))
                 ts = timed(lambda: p.sgs_apply(r, 3, out=z))
