@@ -1054,8 +1054,8 @@ int blasted_hip_set_tuning(const char *spec)
 	return guarded([&] {
 		if (spec && std::strncmp(spec, "level=", 6) == 0)
 			g_level_impl = std::strcmp(spec + 6, "launch") == 0 ? 1 : 0;
-		else if (spec && std::strncmp(spec, "sweep5=", 7) == 0)
-			set_sweep5_enabled(spec[7] != '0');
+		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
+			set_sweepodd_enabled(spec[9] != '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)

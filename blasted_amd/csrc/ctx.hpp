@@ -108,9 +108,9 @@ void set_sweep_unroll(int u);
 // kernels_sweepw.hip (tuned bs=4/8 column-major path; false = not covered, use the generic family)
 bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepw_variant(const char *spec);
-// kernels_sweep5.hip (tuned bs=5 column-major path; false = not covered)
-bool launch_sweep5(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
-void set_sweep5_enabled(int on);
+// kernels_sweepodd.hip (tuned bs=3/5/7 column-major path; false = not covered)
+bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+void set_sweepodd_enabled(int on);
 // kernels_level.hip (exact in-order passes, one launch per dependency level)
 void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void free_level_schedule(LevelSchedule &ls);

@@ -275,7 +275,7 @@ void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream
 {
 	if (launch_sweepw(a, part, post, dsrc, s))
 		return;
-	if (launch_sweep5(a, part, post, dsrc, s))
+	if (launch_sweepodd(a, part, post, dsrc, s))
 		return;
 	switch (a.pat.bs) {
 	case 1: dispatch_layout<1>(a, part, post, dsrc, s); break;

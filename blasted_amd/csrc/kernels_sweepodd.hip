@@ -1,16 +1,18 @@
-// kernels_sweep5.hip -- the tuned row-sweep kernel for column-major 5x5 blocks: the reference's other
-// stock block size (src/solverops_ilu0.cpp:385-395, the 3-D compressible-flow case its author targets)
-// and BASELINE.json's config 4.  Same operators and arithmetic as the generic family in
-// kernels_sweep.hip (table there); the generic kernel pads a 5x5 block to an 8x8 lane tile, so one
-// wave load instruction moves a single 200-byte block -- this kernel moves four:
+// kernels_sweepodd.hip -- the tuned row-sweep kernel for column-major blocks of odd size 3, 5, 7.
+// bs = 5 is the reference's other stock block size (src/solverops_ilu0.cpp:385-395, the 3-D
+// compressible-flow case its author targets) and BASELINE.json's config 4; 3 and 7 are the sizes of its
+// SpMV fixtures.  Same operators and arithmetic as the generic family in kernels_sweep.hip (table
+// there); the generic kernel pads a block to a power-of-two lane tile, so one wave load instruction
+// moves a single 5x5 (7x7) block or four 3x3 blocks -- this kernel moves 4 (2, 8) blocks, 16 bytes per lane:
 //
-//  * 16 lanes own one block-row, 13 of them one stored block per pass: lane q < 12 reads entries
-//    (2q, 2q+1) as 16 bytes, lane 12 reads (23, 24) and uses 24.  A block starts at a multiple of 200
-//    bytes, so half of these loads are 8- but not 16-byte aligned (gfx950 global loads take that);
+//  * G = 8 / 16 / 32 lanes own one block-row, L = (bs*bs+1)/2 = 5 / 13 / 25 of them one stored block
+//    per pass: lane q < L-1 reads entries (2q, 2q+1) as 16 bytes, the last lane reads the block's last
+//    two entries and uses the second.  A block starts at a multiple of 8*bs*bs bytes, so half of these
+//    loads are 8- but not 16-byte aligned (gfx950 global loads take that);
 //  * the x segment is gathered as 16 bytes per lane too: the two entries of a lane lie in column c or
-//    in columns c, c+1 of the block, so (x_c, x_{c+1}) covers both (for c = 4: (x_3, x_4));
-//  * entry e = 5c + r contributes to component r, which follows no power-of-two lane pattern: the 25
-//    partial products of a row go through a 200-byte LDS tile and five lanes per row sum their
+//    in columns c, c+1 of the block, so (x_c, x_{c+1}) covers both (last column: (x_{bs-2}, x_{bs-1}));
+//  * entry e = bs*c + r contributes to component r, which follows no power-of-two lane pattern: the
+//    partial products of a row go through a (bs*bs)-double LDS tile and bs lanes per row sum their
 //    component's column (wave-private tile: LDS executes a wave's instructions in order, no barrier);
 //    the diagonal-block product of the upper solve / Gauss-Seidel goes the same way;
 //  * row chunk, LDS-staged browptr / diagind / bcolind range, straight-line predicated block passes,
@@ -38,11 +40,15 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 	return __builtin_nontemporal_load(reinterpret_cast<const d2u_t *>(p));
 }
 
-template <int PART, int POST, int DSRC, int RCHUNK>
-__global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
+template <int BS, int PART, int POST, int DSRC, int RCHUNK>
+__global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 {
-	constexpr int BS = 5, BS2 = 25, RPW = 4, RSTEP = 16, CAP = 16 * RCHUNK;
+	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
+	constexpr int BS2 = BS * BS, L = (BS2 + 1) / 2;     // lanes that hold a block
+	constexpr int G = BS == 3 ? 8 : (BS == 5 ? 16 : 32);  // lanes per block-row
+	constexpr int RPW = 64 / G, RSTEP = 4 * RPW, CAP = (BS == 3 ? 8 : 16) * RCHUNK;
 	constexpr int BLKBYTES = BS2 * 8, ROWBYTES = BS * 8;
+	static_assert(RCHUNK % RSTEP == 0, "chunk must be a multiple of the row step");
 	constexpr int KFIX = (PART == PART_ALL || PART == PART_OFFDIAG) ? 8 : 4;
 	constexpr bool DIAG_RIDES = PART == PART_UPPER && DSRC == D_VALS_DIAG;
 	constexpr bool USES_D = POST == POST_D_SUB || POST == POST_SUB_D;
@@ -50,17 +56,17 @@ __global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
 	__shared__ int s_rp[RCHUNK + 1];
 	__shared__ int s_dg[RCHUNK];
 	__shared__ int s_col[CAP];
-	__shared__ double s_acc[4][RPW][26];  // [wave][row of the step][entry]
-	__shared__ double s_w[4][RPW][6];
+	__shared__ double s_acc[4][RPW][BS2 + 1];  // [wave][row of the step][entry]
+	__shared__ double s_w[4][RPW][BS + 1];
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
-	const int g = lane >> 4, t = lane & 15;
-	const bool actA = t < 12, actB = t < 13;
-	const int eA = actA ? 2 * t : 23, eB = actA ? 2 * t + 1 : 24;
-	const unsigned boff = actA ? 16u * (unsigned)t : 184u;  // lane 12: entries (23, 24)
-	const int cA = eA / 5, cB = eB / 5;
-	const int cx = cA < 3 ? cA : 3;  // gathered pair (x_cx, x_cx+1)
+	const int g = lane / G, t = lane % G;
+	const bool actA = t < L - 1, actB = t < L;
+	const int eA = actA ? 2 * t : BS2 - 2, eB = actA ? 2 * t + 1 : BS2 - 1;
+	const unsigned boff = actA ? 16u * (unsigned)t : 8u * (unsigned)(BS2 - 2);  // last lane: the last two entries
+	const int cA = (eA / BS) < BS ? eA / BS : BS - 1, cB = (eB / BS) < BS ? eB / BS : BS - 1;
+	const int cx = cA < BS - 2 ? cA : BS - 2;  // gathered pair (x_cx, x_cx+1)
 	const bool hiA = cA != cx, hiB = cB != cx;
 
 	const int nb = a.pat.nbrows;
@@ -179,8 +185,11 @@ __global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
 			if (actB)
 				tile[eB] = accB;
 			__builtin_amdgcn_wave_barrier();
-			if (t < BS)
-				sum = tile[t] + tile[5 + t] + tile[10 + t] + tile[15 + t] + tile[20 + t];
+			if (t < BS) {
+#pragma unroll
+				for (int cc = 0; cc < BS; cc++)
+					sum += tile[cc * BS + t];
+			}
 			__builtin_amdgcn_wave_barrier();
 		}
 
@@ -199,8 +208,11 @@ __global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
 				tile[eB] = dv.y * wB;
 			__builtin_amdgcn_wave_barrier();
 			double pr = 0.0;
-			if (t < BS)
-				pr = tile[t] + tile[5 + t] + tile[10 + t] + tile[15 + t] + tile[20 + t];
+			if (t < BS) {
+#pragma unroll
+				for (int cc = 0; cc < BS; cc++)
+					pr += tile[cc * BS + t];
+			}
 			__builtin_amdgcn_wave_barrier();
 			out = (POST == POST_D_SUB) ? pr : rv - pr;
 		} else {
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(256) void sweep5_kernel(const SweepArgs a)
 	}
 }
 
-int g_sweep5_enabled = [] {
-	const char *e = std::getenv("BLASTED_HIP_SWEEP5");
+int g_sweepodd_enabled = [] {
+	const char *e = std::getenv("BLASTED_HIP_SWEEPODD");
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 }();
 
@@ -224,21 +236,27 @@ void launch5(const SweepArgs &a, hipStream_t s)
 {
 	constexpr int RCHUNK = 128;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
-	hipLaunchKernelGGL((sweep5_kernel<PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a);
+	switch (a.pat.bs) {
+	case 3: hipLaunchKernelGGL((sweepodd_kernel<3, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
+	case 5: hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
+	default: hipLaunchKernelGGL((sweepodd_kernel<7, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
+	}
 }
 
 }  // namespace
 
-void set_sweep5_enabled(int on)
+void set_sweepodd_enabled(int on)
 {
-	g_sweep5_enabled = on;
+	g_sweepodd_enabled = on;
 }
 
 // returns false when the tuned kernel does not cover the request (caller uses the generic family)
-bool launch_sweep5(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
+bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
-	if (!g_sweep5_enabled || a.pat.bs != 5 || a.pat.rowmajor || a.pat.nbrows == 0 || a.changed)
+	const int bs = a.pat.bs;
+	if (!g_sweepodd_enabled || (bs != 3 && bs != 5 && bs != 7) || a.pat.rowmajor || a.pat.nbrows == 0 || a.changed)
 		return false;
+	// 8-byte aligned arrays are all this kernel needs
 	bool ok = true;
 #define BHIP_CASE5(P, Q, D)                           \
 	if (part == P && post == Q && dsrc == D)          \

@@ -25,7 +25,7 @@ def main():
     cases = [("poisson128 bs5", lambda: W.poisson3d_device(128, 5, dev, grid="uniform")),
              ("poisson128 bs7", lambda: W.poisson3d_device(128, 7, dev, grid="uniform")),
              ("unstructured126 bs5", lambda: W.unstructured_bsr(126, 5, device=dev)),
-             ("poisson160 bs1", lambda: W.poisson3d_device(160, 1, dev, grid="uniform"))]
+             ("poisson160 bs3", lambda: W.poisson3d_device(160, 3, dev, grid="uniform"))]
     for name, gen in cases:
         m = gen()
         bs = m["bs"]
@@ -38,7 +38,7 @@ def main():
         nnzb, nb = m["nnzb"], m["nbrows"]
         pair_bytes = (nnzb * (8 * bs * bs + 4)) + 4 * nb * 4 + 6 * nb * 8 * bs
         for rep in range(2):
-            for spec in ("sweep5=0", "sweep5=1"):
+            for spec in ("sweepodd=0", "sweepodd=1"):
                 capi.set_tuning(spec)
                 t = timed(lambda: p.ilu0_apply(r, 3, out=z))
                 ts = timed(lambda: p.sgs_apply(r, 3, out=z))
