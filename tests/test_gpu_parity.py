@@ -365,7 +365,7 @@ def test_solve_known_answer_on_gpu(golden, mat, bs, rowmajor, prec):
 
 def test_tiny_and_ragged_matrices():
     # 1 block-row; rows with empty lower / upper parts; row count not a multiple of the rows per workgroup
-    for nb, bs in ((1, 4), (2, 5), (3, 1), (17, 4), (65, 8), (5, 3)):
+    for nb, bs in ((1, 4), (2, 5), (3, 1), (17, 4), (65, 8), (5, 3), (129, 7), (33, 3), (131, 5), (9, 2)):
         m = W.random_bsr(nb, bs, avg_offdiag=2, seed=nb)
         n = nb * bs
         r = W.rhs_vector(n)
@@ -376,6 +376,12 @@ def test_tiny_and_ragged_matrices():
         assert rel(p.get_iluvals(), f) < TOL_EXACT
         z = p.ilu0_apply(r, nb + 2)
         assert rel(z, O.ilu0_apply(m, f, r, 1)) < TOL_EXACT
+        assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), O.ilu0_apply(m, f, r, 1)) < TOL_EXACT
+        p.ilu0_factorize(-1)
+        assert rel(p.get_iluvals(), f) < TOL_EXACT
+        p.jacobi_compute()
+        assert rel(p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC),
+                   O.sgs_apply(m, p.get_dblocks(), r, 2, mode=O.JACOBI_SYNC)) < TOL_SYNC
         p.close()
 
 
