@@ -220,4 +220,17 @@ def test_config4_config5(cfg):
     za = p.ilu0_apply(r, nsw, mode=capi.ASYNC)
     zb = p.ilu0_apply(r, nsw + 1, mode=capi.ASYNC)
     assert relmax(za, zb) < 1e-12
+    # the exact forms reach the same fixed points in one pass: level-scheduled factorisation and solves
+    fa = torch.from_numpy(p.get_iluvals()).to(dev)
+    info = p.ilu0_factorize(-1, compute_info=True)
+    assert info[0] < 1e-14 * info[1]
+    fe = torch.from_numpy(p.get_iluvals()).to(dev)
+    assert relmax(fa, fe) < 1e-9
+    del fa
+    ze = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+    assert relmax(za, ze) < 1e-9
+    y = torch.from_numpy(p.get_ytemp()).to(dev)
+    assert relmax(y, r - torch_part_matvec(m, fe, y, "lower")) < 1e-12
+    st = p.level_stats()
+    assert st["syncfree_aborts"] == 0 and st["syncfree_passes"] >= 2
     p.close()
