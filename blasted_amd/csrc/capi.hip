@@ -178,18 +178,52 @@ static int g_level_impl = [] {
 	return (e && std::strcmp(e, "launch") == 0) ? 1 : 0;
 }();
 
+// 1: exact triangular solves with the factor stream from level-ordered copies of its two triangles
+// (contiguous reads; costs a second copy of the factor and one permutation pass per factorisation)
+static int g_level_store = [] {
+	const char *e = std::getenv("BLASTED_HIP_LEVELSTORE");
+	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
+}();
+
+// The level-ordered view of the factor's lower or diagonal+upper triangle, refreshed after a
+// factorisation; false when the copies are switched off.
+static bool factor_view(blasted_hip_prec p, bool upper, LevelView &v)
+{
+	if (!g_level_store)
+		return false;
+	LevelSchedule &ls = need_levels(p);
+	build_level_storage(p->pat, ls, p->stream);
+	const long bs2 = (long)p->pat.bs * p->pat.bs;
+	if (!p->lfac) {
+		p->lfac = dev_alloc<double>((size_t)(ls.nnz_lower * bs2));
+		p->ufac = dev_alloc<double>((size_t)(ls.nnz_dupper * bs2));
+		p->lfac_valid = false;
+	}
+	if (!p->lfac_valid) {
+		launch_level_permute_values(p->pat, ls, p->iluvals, p->lfac, p->ufac, p->stream);
+		p->lfac_valid = true;
+	}
+	v.meta = upper ? ls.umeta : ls.lmeta;
+	v.ptr = upper ? ls.uptr : ls.lptr;
+	v.bcolind = upper ? ls.ucol : ls.lcol;
+	v.vals = upper ? p->ufac : p->lfac;
+	return true;
+}
+
 // One exact in-order pass of an operator producing `x` (for relaxation: from the previous iterate
 // `xold`, a different vector; otherwise xold is ignored).  Returns the number of launches.
 static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSrc dsrc, double *x,
                       const double *xold)
 {
 	LevelSchedule &ls = need_levels(p);
-	a.changed = nullptr;
 	if (g_level_impl == 0) {
+		LevelView view;
+		const bool triangular = part == PART_LOWER || part == PART_UPPER;
+		const bool use_view = triangular && a.vals == p->iluvals && factor_view(p, part == PART_UPPER, view);
 		launch_syncfree_fill(x, p->n(), p->stream);
 		a.xin = xold ? xold : x;
 		a.xout = x;
-		if (launch_syncfree_sweep(a, part, post, dsrc, ls, p->stream)) {
+		if (launch_syncfree_sweep(a, part, post, dsrc, ls, p->stream, use_view ? &view : nullptr)) {
 			// the pass is only valid if no wave gave up waiting: look at the abort flag before going on
 			int ctl[2] = {0, 0};
 			BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, p->stream));
@@ -331,8 +365,9 @@ int blasted_hip_destroy(blasted_hip_prec p)
 			dev_free(p->stage[i]);
 		}
 		dev_free(p->red);
-		dev_free(p->flags);
 		free_level_schedule(p->levels);
+		dev_free(p->lfac);
+		dev_free(p->ufac);
 		if (p->own_stream)
 			(void)hipStreamDestroy(p->stream);
 		delete p;
@@ -484,6 +519,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
+		p->lfac_valid = false;
 		if (mode == BLASTED_HIP_LEVEL)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
 			                              "points; the exact factorisation is nbuildsweeps < 0");
@@ -525,7 +561,6 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.posptr = p->posptr;
 		fa.lowerp = p->lowerp;
 		fa.upperp = p->upperp;
-		fa.changed = nullptr;
 		fa.rows = nullptr;
 		fa.nrows = 0;
 		fa.dinv_scratch = nullptr;
@@ -1052,7 +1087,11 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 int blasted_hip_set_tuning(const char *spec)
 {
 	return guarded([&] {
-		if (spec && std::strncmp(spec, "level=", 6) == 0)
+		if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
+			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "levelstore=", 11) == 0)
+			g_level_store = spec[11] != '0';
+		else if (spec && std::strncmp(spec, "level=", 6) == 0)
 			g_level_impl = std::strcmp(spec + 6, "launch") == 0 ? 1 : 0;
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
 			set_sweepodd_enabled(spec[9] != '0');

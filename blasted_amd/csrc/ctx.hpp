@@ -67,7 +67,6 @@ struct SweepArgs {
 	double *xout;           // written iterate (== xin for in-place async sweeps)
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
-	int *changed;           // optional flag: set to 1 if any stored value differs from the old one
 };
 
 // Level schedule of a pattern (kernels_level.hip): rows sorted by dependency depth
@@ -85,6 +84,22 @@ struct LevelSchedule {
 	int max_lower = 0, max_upper = 0;  // longest strictly-lower / strictly-upper row part
 	int sf_grid = 1024;                // workgroups of a persistent launch
 	long sf_launches = 0, sf_aborts = 0;
+	// level-ordered compact copies of the two triangles (pattern part; values live in the operator):
+	// position p of the level order owns blocks [lptr[p], lptr[p+1]) of the strictly-lower copy and
+	// [uptr[p], uptr[p+1]) of the diagonal+upper copy, so an exact pass streams contiguous memory
+	bool storage_built = false;
+	int *lptr = nullptr, *uptr = nullptr;    // device, nbrows + 1
+	int *lcol = nullptr, *ucol = nullptr;    // device, nnzL / nnzU + nbrows
+	int4 *lmeta = nullptr, *umeta = nullptr; // device, nbrows: {row, lptr[p], lptr[p+1], -} / {row, -, uptr[p], uptr[p+1]}
+	long nnz_lower = 0, nnz_dupper = 0;
+};
+
+// Arrays a single-launch pass reads instead of the natural-order ones (level-ordered copies)
+struct LevelView {
+	const int4 *meta = nullptr;
+	const int *ptr = nullptr;
+	const int *bcolind = nullptr;
+	const double *vals = nullptr;
 };
 
 struct FactorArgs {
@@ -94,7 +109,6 @@ struct FactorArgs {
 	const int *posptr, *lowerp, *upperp;
 	const double *in;       // factor values read
 	double *out;            // factor values written (== in for async)
-	int *changed;           // optional flag, as in SweepArgs
 	double *dinv_scratch;   // optional nbrows*bs*bs scratch (bs=8 tuned path: inverted diagonal blocks)
 	const int *rows;        // optional row list (level-scheduled exact factorisation), else all rows
 	int nrows;              // length of `rows`
@@ -118,7 +132,14 @@ int launch_level_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, cons
                        hipStream_t s);
 void launch_syncfree_fill(double *x, long n, hipStream_t s);
 bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
-                           hipStream_t s);
+                           hipStream_t s, const LevelView *view = nullptr);
+// kernels_levelw.hip (streaming exact triangular pass, column-major bs 4 / 8, level-ordered copies)
+bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
+                          hipStream_t s);
+void set_levelw_enabled(int on);
+void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
+void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals,
+                                 double *lvals, double *uvals, hipStream_t s);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);
@@ -182,9 +203,10 @@ struct blasted_hip_prec_s {
 	double *tmp[3] = {nullptr, nullptr, nullptr};    // n-vectors: Jacobi-sync ping-pong
 	double *stage[3] = {nullptr, nullptr, nullptr};  // n-vectors: device copies of host vectors
 	double *red = nullptr;                           // small reduction scratch
-	int *flags = nullptr;                            // per-sweep 'changed' flags (sequential variants)
 
 	bhip::LevelSchedule levels;
+	double *lfac = nullptr, *ufac = nullptr;  // level-ordered copies of the factor's triangles
+	bool lfac_valid = false;
 
 	bhip::Timing timing;
 

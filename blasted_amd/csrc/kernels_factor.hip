@@ -16,6 +16,7 @@
 // the lanes of the group: no LDS allocation, no partial result ever leaves registers, and every entry
 // of iluvals is stored exactly once per sweep (kernels_ilu0_factorize.hpp:34-40).
 #include "ctx.hpp"
+#include "lanes.hpp"
 
 namespace bhip {
 
@@ -26,13 +27,6 @@ struct FGeo {
 	static constexpr int RPW = 64 / SUB;
 	static constexpr int RPB = 4 * RPW;
 };
-
-__device__ __forceinline__ unsigned xcd_chunk_f(unsigned bid, unsigned nwg)
-{
-	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
-}
 
 // Lane (r,c) of a group holds a(r,c) of a BS x BS matrix (lanes with r>=BS or c>=BS hold anything).
 // Returns inverse(r,c) in lane (r,c).  n<=4: adjugate / determinant (the closed form Eigen's
@@ -134,7 +128,7 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 	const int e = RM ? r * BS + c : c * BS + r;
 	const int gbase = lane & ~(SUB - 1);
 
-	const unsigned chunk = xcd_chunk_f(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
 	const long rowlin = (long)chunk * Ge::RPB + wave * Ge::RPW + g;
 	const bool rowok = rowlin < (a.rows ? a.nrows : a.pat.nbrows);
 	const int irow = rowok ? (a.rows ? a.rows[rowlin] : (int)rowlin) : 0;
@@ -190,14 +184,9 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 					res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
 				}
 			}
-			if (active) {
-				if (a.changed && !(a.out[(long)jpos * BS2 + e] == res))
-					*a.changed = 1;
+			if (active)
 				a.out[(long)jpos * BS2 + e] = res;
-			}
 		} else if (active) {
-			if (a.changed && !(a.out[(long)jpos * BS2 + e] == s))
-				*a.changed = 1;
 			a.out[(long)jpos * BS2 + e] = s;
 		}
 	}
@@ -535,7 +524,6 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	if (a.in != a.out)
 		BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_factor_levels: in place only");
 	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels are inverted on the fly
-	a.changed = nullptr;
 	for (int l = 0; l < ls.nlevels; l++) {
 		a.rows = ls.rows + ls.ptr[l];
 		a.nrows = ls.ptr[l + 1] - ls.ptr[l];

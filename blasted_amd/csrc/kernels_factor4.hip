@@ -22,6 +22,7 @@
 //    LDS once, coalesced; no value load waits on an index load from HBM.
 // Every entry of the factor is produced in registers and stored once per sweep.
 #include "ctx.hpp"
+#include "lanes.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -33,13 +34,6 @@ namespace {
 constexpr int F4_RCHUNK = 64;             // rows per workgroup
 constexpr int F4_CAPB = 16 * F4_RCHUNK;   // staged block positions (column index + posptr)
 constexpr int F4_CAPP = 16 * F4_RCHUNK;   // staged (lower, upper) pairs
-
-__device__ __forceinline__ unsigned xcd_chunk_f4(unsigned bid, unsigned nwg)
-{
-	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
-}
 
 __device__ __forceinline__ double mfma444(const double a, const double b, const double c)
 {
@@ -88,7 +82,7 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 	const int offD = m * 4 + k;  // element (r = k, c = m)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk_f4(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
 	const int r0 = (int)chunk * F4_RCHUNK;
 	const int rc = (nb - r0) < F4_RCHUNK ? (nb - r0) : F4_RCHUNK;
 
@@ -179,8 +173,6 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 
 			if (valid) {
 				double *const dst = a.out + (long)jpos * 16 + offD;
-				if (a.changed && !(*dst == res))
-					*a.changed = 1;
 				*dst = res;
 			}
 		}

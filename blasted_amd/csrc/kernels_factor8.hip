@@ -23,6 +23,7 @@
 // All control flow is wave-uniform (a wave walks one block-row); indices of a 32-row chunk are staged in
 // LDS; each entry of the factor is produced in registers and stored once.
 #include "ctx.hpp"
+#include "lanes.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -34,13 +35,6 @@ namespace {
 constexpr int F8_RCHUNK = 32;
 constexpr int F8_CAPB = 16 * F8_RCHUNK;
 constexpr int F8_CAPP = 16 * F8_RCHUNK;
-
-__device__ __forceinline__ unsigned xcd_chunk_f8(unsigned bid, unsigned nwg)
-{
-	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
-}
 
 __device__ __forceinline__ double mfma444(const double a, const double b, const double c)
 {
@@ -69,7 +63,7 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 	const int srcA1 = 16 * m + 4 * (2 * ti + 1) + k;   // lane holding S(4ti+m, 4+k)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk_f8(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
 	const int r0 = (int)chunk * F8_RCHUNK;
 	const int rc = (nb - r0) < F8_RCHUNK ? (nb - r0) : F8_RCHUNK;
 
@@ -150,8 +144,6 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 			}
 
 			double *const dst = a.out + (long)jpos * 64 + offD;
-			if (a.changed && !(*dst == res))
-				*a.changed = 1;
 			*dst = res;
 		}
 	}

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 }
 
 template <int BS, bool RM, int PART, int POST, int DSRC>
-bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStream_t s)
+bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStream_t s, const int4 *meta)
 {
 	constexpr int NB = Geo<BS>::NB, RPW = Geo<BS>::RPW;
 	const int passes = (need + NB - 1) / NB;
@@ -430,7 +430,7 @@ bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStre
 		const long grid = ((long)ls.count + per_wg - 1) / per_wg;                                           \
 		if (grid > 0)                                                                                       \
 			hipLaunchKernelGGL((sf_sweep_kernel<BS, RM, PART, POST, DSRC, K, STEPS>), dim3((unsigned)grid), \
-			                   dim3(256), 0, s, a, ls.meta, ls.count, ls.ctl);                              \
+			                   dim3(256), 0, s, a, meta, ls.count, ls.ctl);                                 \
 		return true;                                                                                        \
 	}
 	BHIP_KF(4, 4)
@@ -441,12 +441,13 @@ bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStre
 }
 
 template <int BS, bool RM>
-bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls, hipStream_t s)
+bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls, hipStream_t s,
+                     const int4 *meta)
 {
 	const int lo = ls.max_lower, up = ls.max_upper;
 #define BHIP_CASE(P, Q, D, NEED)                                       \
 	if (part == P && post == Q && dsrc == D)                           \
-		return sf_launch_kf<BS, RM, P, Q, D>(a, ls, NEED, s);
+		return sf_launch_kf<BS, RM, P, Q, D>(a, ls, NEED, s, meta);
 	BHIP_CASE(PART_LOWER, POST_SUB, D_NONE, lo)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_VALS_DIAG, up + 1)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_RECIP_DIAG, up + 1)
@@ -459,12 +460,67 @@ bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const 
 
 template <int BS>
 bool sf_dispatch_layout(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
-                        hipStream_t s)
+                        hipStream_t s, const int4 *meta)
 {
 	if (BS > 1 && a.pat.rowmajor)
-		return sf_dispatch_ops<BS, true>(a, part, post, dsrc, ls, s);
-	return sf_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s);
+		return sf_dispatch_ops<BS, true>(a, part, post, dsrc, ls, s, meta);
+	return sf_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s, meta);
 }
+
+// level-ordered storage: per-position block counts of the two triangles
+__global__ __launch_bounds__(256) void level_counts_kernel(const Pattern pat, const int *rows, int *cl, int *cu)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= pat.nbrows)
+		return;
+	const int row = rows[k];
+	const int dg = pat.diagind[row];
+	cl[k] = dg - pat.browptr[row];
+	cu[k] = pat.browptr[row + 1] - dg;
+}
+
+// column indices in level order + the descriptors of the two copies
+__global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, const int *rows, const int *lptr,
+                                                         const int *uptr, int *lcol, int *ucol, int4 *lmeta,
+                                                         int4 *umeta)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= pat.nbrows)
+		return;
+	const int row = rows[k];
+	const int rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
+	const int l0 = lptr[k], u0 = uptr[k];
+	for (int jj = rp0; jj < dg; jj++)
+		lcol[l0 + (jj - rp0)] = pat.bcolind[jj];
+	for (int jj = dg; jj < rp1; jj++)
+		ucol[u0 + (jj - dg)] = pat.bcolind[jj];
+	lmeta[k] = make_int4(row, l0, l0 + (dg - rp0), 0);
+	umeta[k] = make_int4(row, 0, u0, u0 + (rp1 - dg));
+}
+
+// values of the two triangles into level order: 16 lanes move one row, 8 bytes per lane and step
+template <int BS2>
+__global__ __launch_bounds__(256) void level_permute_kernel(const Pattern pat, const int *rows, const int *lptr,
+                                                            const int *uptr, const double *__restrict__ vals,
+                                                            double *__restrict__ lvals, double *__restrict__ uvals)
+{
+	const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
+	const int t = threadIdx.x & 15;
+	if (k >= pat.nbrows)
+		return;
+	const int row = rows[k];
+	const long rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
+	const long nl = (dg - rp0) * BS2, nu = (rp1 - dg) * BS2;
+	const double *const srcl = vals + rp0 * BS2;
+	const double *const srcu = vals + dg * BS2;
+	double *const dstl = lvals + (long)lptr[k] * BS2;
+	double *const dstu = uvals + (long)uptr[k] * BS2;
+	for (long q = t; q < nl; q += 16)
+		dstl[q] = srcl[q];
+	for (long q = t; q < nu; q += 16)
+		dstu[q] = srcu[q];
+}
+
 
 template <typename T>
 T *lvl_alloc(size_t count)
@@ -486,6 +542,10 @@ void free_level_schedule(LevelSchedule &ls)
 		(void)hipFree(ls.meta);
 	if (ls.ctl)
 		(void)hipFree(ls.ctl);
+	for (void *q : {(void *)ls.lptr, (void *)ls.uptr, (void *)ls.lcol, (void *)ls.ucol, (void *)ls.lmeta,
+	                (void *)ls.umeta})
+		if (q)
+			(void)hipFree(q);
 	ls = LevelSchedule();
 }
 
@@ -621,9 +681,20 @@ void launch_syncfree_fill(double *x, long n, hipStream_t s)
 // launch_syncfree_fill; a.xin (relaxation: the previous iterate) must be a different, complete vector.
 // Returns false when a row part is too long for the register-held passes (caller uses
 // launch_level_sweep).  The abort flag ls.ctl[1] must be checked by the caller after the stream drains.
-bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
-                           hipStream_t s)
+bool launch_syncfree_sweep(const SweepArgs &a_, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
+                           hipStream_t s, const LevelView *view)
 {
+	SweepArgs a = a_;
+	const int4 *meta = ls.meta;
+	if (view) {  // level-ordered copies: contiguous stream
+		meta = view->meta;
+		a.vals = view->vals;
+		a.pat.bcolind = view->bcolind;
+		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
+		const bool ilu_upper = part == PART_UPPER && post == POST_D_SUB && dsrc == D_VALS_DIAG;
+		if ((ilu_lower || ilu_upper) && launch_syncfree_wide(a, ilu_upper, ls, view->ptr, view->bcolind, s))
+			return true;
+	}
 	if (!ls.built)
 		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_syncfree_sweep: no level schedule");
 	if (part == PART_OFFDIAG && a.xin == a.xout)
@@ -631,17 +702,99 @@ bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 	bool ok = false;
 	switch (a.pat.bs) {
-	case 1: ok = sf_dispatch_layout<1>(a, part, post, dsrc, ls, s); break;
-	case 2: ok = sf_dispatch_layout<2>(a, part, post, dsrc, ls, s); break;
-	case 3: ok = sf_dispatch_layout<3>(a, part, post, dsrc, ls, s); break;
-	case 4: ok = sf_dispatch_layout<4>(a, part, post, dsrc, ls, s); break;
-	case 5: ok = sf_dispatch_layout<5>(a, part, post, dsrc, ls, s); break;
-	case 7: ok = sf_dispatch_layout<7>(a, part, post, dsrc, ls, s); break;
-	case 8: ok = sf_dispatch_layout<8>(a, part, post, dsrc, ls, s); break;
+	case 1: ok = sf_dispatch_layout<1>(a, part, post, dsrc, ls, s, meta); break;
+	case 2: ok = sf_dispatch_layout<2>(a, part, post, dsrc, ls, s, meta); break;
+	case 3: ok = sf_dispatch_layout<3>(a, part, post, dsrc, ls, s, meta); break;
+	case 4: ok = sf_dispatch_layout<4>(a, part, post, dsrc, ls, s, meta); break;
+	case 5: ok = sf_dispatch_layout<5>(a, part, post, dsrc, ls, s, meta); break;
+	case 7: ok = sf_dispatch_layout<7>(a, part, post, dsrc, ls, s, meta); break;
+	case 8: ok = sf_dispatch_layout<8>(a, part, post, dsrc, ls, s, meta); break;
 	default: BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "block size not instantiated (1,2,3,4,5,7,8)");
 	}
 	BHIP_CHECK(hipGetLastError());
 	return ok;
+}
+
+// Pattern part of the level-ordered storage (once per pattern).
+void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
+{
+	if (!ls.built)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "build_level_storage: no level schedule");
+	if (ls.storage_built)
+		return;
+	const int n = pat.nbrows;
+	if (n == 0) {
+		ls.storage_built = true;
+		return;
+	}
+	const unsigned grid = (unsigned)((n + 255) / 256);
+	int *cl = lvl_alloc<int>((size_t)n + 1), *cu = lvl_alloc<int>((size_t)n + 1);
+	void *tmp = nullptr;
+	try {
+		BHIP_CHECK(hipMemsetAsync(cl + n, 0, sizeof(int), s));
+		BHIP_CHECK(hipMemsetAsync(cu + n, 0, sizeof(int), s));
+		hipLaunchKernelGGL(level_counts_kernel, dim3(grid), dim3(256), 0, s, pat, ls.rows, cl, cu);
+		ls.lptr = lvl_alloc<int>((size_t)n + 1);
+		ls.uptr = lvl_alloc<int>((size_t)n + 1);
+		size_t bytes = 0;
+		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cl, ls.lptr, n + 1, s));
+		BHIP_CHECK(hipMalloc(&tmp, bytes ? bytes : 1));
+		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cl, ls.lptr, n + 1, s));
+		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cu, ls.uptr, n + 1, s));
+		int tot[2] = {0, 0};
+		BHIP_CHECK(hipMemcpyAsync(&tot[0], ls.lptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipMemcpyAsync(&tot[1], ls.uptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+		ls.nnz_lower = tot[0];
+		ls.nnz_dupper = tot[1];
+		if (ls.nnz_lower + ls.nnz_dupper != pat.nnzb)
+			BHIP_FAIL(BLASTED_HIP_ERUNTIME, "level storage: triangle sizes do not add up (internal error)");
+		ls.lcol = lvl_alloc<int>((size_t)ls.nnz_lower);
+		ls.ucol = lvl_alloc<int>((size_t)ls.nnz_dupper);
+		ls.lmeta = lvl_alloc<int4>(n);
+		ls.umeta = lvl_alloc<int4>(n);
+		hipLaunchKernelGGL(level_cols_kernel, dim3(grid), dim3(256), 0, s, pat, ls.rows, ls.lptr, ls.uptr, ls.lcol,
+		                   ls.ucol, ls.lmeta, ls.umeta);
+		BHIP_CHECK(hipGetLastError());
+		BHIP_CHECK(hipStreamSynchronize(s));
+		ls.storage_built = true;
+	} catch (...) {
+		for (void *q : {(void *)cl, (void *)cu, tmp})
+			if (q)
+				(void)hipFree(q);
+		throw;
+	}
+	for (void *q : {(void *)cl, (void *)cu, tmp})
+		if (q)
+			(void)hipFree(q);
+}
+
+// Values of both triangles into level order (after every factorisation that is applied exactly).
+void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals, double *lvals,
+                                 double *uvals, hipStream_t s)
+{
+	if (!ls.storage_built)
+		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_level_permute_values: no level storage");
+	if (pat.nbrows == 0)
+		return;
+	const unsigned grid = (unsigned)(((long)pat.nbrows + 15) / 16);
+#define BHIP_PERM(B)                                                                                       \
+	case B:                                                                                                \
+		hipLaunchKernelGGL((level_permute_kernel<B * B>), dim3(grid), dim3(256), 0, s, pat, ls.rows, ls.lptr, \
+		                   ls.uptr, vals, lvals, uvals);                                                   \
+		break;
+	switch (pat.bs) {
+		BHIP_PERM(1)
+		BHIP_PERM(2)
+		BHIP_PERM(3)
+		BHIP_PERM(4)
+		BHIP_PERM(5)
+		BHIP_PERM(7)
+		BHIP_PERM(8)
+	default: BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "block size not instantiated (1,2,3,4,5,7,8)");
+	}
+#undef BHIP_PERM
+	BHIP_CHECK(hipGetLastError());
 }
 
 }  // namespace bhip

@@ -207,8 +207,6 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
 			if (ok[q] && slot == 0 && c == 0 && r < BS) {
 				double *const dst = reinterpret_cast<double *>(obase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
-				if (a.changed && !(*dst == out))
-					*a.changed = 1;
 				*dst = out;
 			}
 		}

@@ -254,7 +254,7 @@ void set_sweepodd_enabled(int on)
 bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
 	const int bs = a.pat.bs;
-	if (!g_sweepodd_enabled || (bs != 3 && bs != 5 && bs != 7) || a.pat.rowmajor || a.pat.nbrows == 0 || a.changed)
+	if (!g_sweepodd_enabled || (bs != 3 && bs != 5 && bs != 7) || a.pat.rowmajor || a.pat.nbrows == 0)
 		return false;
 	// 8-byte aligned arrays are all this kernel needs
 	bool ok = true;

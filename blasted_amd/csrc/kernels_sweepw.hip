@@ -266,11 +266,6 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				o2.y = o1;
 				double2_t *const dst = reinterpret_cast<double2_t *>(
 				    obase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q));
-				if (a.changed) {
-					const double2_t old = *dst;
-					if (!(old.x == o0) || !(old.y == o1))
-						*a.changed = 1;
-				}
 				*dst = o2;
 			}
 		}

@@ -173,7 +173,10 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
  * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
  * "sweepodd=0" / "sweepodd=1": tuned bs=3/5/7 sweep kernel off / on (environment: BLASTED_HIP_SWEEPODD).
  * "level=syncfree" (default) / "level=launch": exact passes as one persistent launch or as one launch
- * per dependency level (environment: BLASTED_HIP_LEVEL). */
+ * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":
+ * exact triangular solves read level-ordered copies of the factor's triangles (one extra copy of the
+ * factor, permuted once per factorisation) or the factor in place (environment: BLASTED_HIP_LEVELSTORE);
+ * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8. */
 int blasted_hip_set_tuning(const char *spec);
 
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */

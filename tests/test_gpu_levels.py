@@ -23,19 +23,24 @@ CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16
          "random_bs4", "random_csr"]
 
 
-@pytest.fixture(params=["syncfree", "launch"], autouse=True)
+@pytest.fixture(params=["syncfree", "syncfree_general", "syncfree_inplace", "launch"], autouse=True)
 def level_impl(request):
-    """Every test runs with both implementations of an exact pass: one persistent launch that polls its
-    dependencies (default) and one launch per level."""
-    capi.set_tuning("level=" + request.param)
+    """Every test runs with each implementation of an exact pass: one launch that polls its dependencies
+    -- the streaming kernel on level-ordered copies of the factor (default, bs 4/8 column-major), the
+    general kernel on those copies, the general kernel on the factor in place -- and one launch per level."""
+    capi.set_tuning("level=" + ("launch" if request.param == "launch" else "syncfree"))
+    capi.set_tuning("levelstore=" + ("0" if request.param == "syncfree_inplace" else "1"))
+    capi.set_tuning("levelwide=" + ("0" if request.param == "syncfree_general" else "1"))
     yield request.param
     capi.set_tuning("level=syncfree")
+    capi.set_tuning("levelstore=1")
+    capi.set_tuning("levelwide=1")
 
 
 def check_stats(p, impl):
     st = p.level_stats()
     assert st["syncfree_aborts"] == 0
-    assert (st["syncfree_passes"] > 0) == (impl == "syncfree")
+    assert (st["syncfree_passes"] > 0) == (impl != "launch")
 
 
 def one_sided(m):

@@ -38,7 +38,13 @@ def main():
     print("nbrows %d bs %d: %d levels, schedule built in %.1f ms" % (m["nbrows"], bs, nl, (time.perf_counter() - t0) * 1e3))
     print("ilu factor exact      %8.3f ms" % timed(lambda: p.ilu0_factorize(-1), 2))
     print("ilu factor ASYNC s=3  %8.3f ms" % timed(lambda: p.ilu0_factorize(3), 2))
-    print("ilu apply  LEVEL      %8.3f ms" % timed(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z), 5))
+    print("ilu apply  LEVEL      %8.3f ms" % timed(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z), 5), p.level_stats())
+    if bs in (4, 8):
+        for spec in ("levelwide=0", "levelstore=0", "level=launch"):
+            capi.set_tuning(spec)
+            print("   %-14s      %8.3f ms" % (spec, timed(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z), 5)))
+        for spec in ("levelwide=1", "levelstore=1", "level=syncfree"):
+            capi.set_tuning(spec)
     for s in (1, 3, 10):
         print("ilu apply  ASYNC s=%-2d %8.3f ms" % (s, timed(lambda: p.ilu0_apply(r, s, out=z), 5)))
     print("sgs apply  LEVEL      %8.3f ms" % timed(lambda: p.sgs_apply(r, 1, mode=capi.LEVEL, out=z), 5))
