@@ -205,6 +205,7 @@ static bool factor_view(blasted_hip_prec p, bool upper, LevelView &v)
 	}
 	v.meta = upper ? ls.umeta : ls.lmeta;
 	v.ptr = upper ? ls.uptr : ls.lptr;
+	v.head = upper ? ls.uhead : ls.lhead;
 	v.bcolind = upper ? ls.ucol : ls.lcol;
 	v.vals = upper ? p->ufac : p->lfac;
 	return true;

@@ -91,12 +91,14 @@ struct LevelSchedule {
 	int *lptr = nullptr, *uptr = nullptr;    // device, nbrows + 1
 	int *lcol = nullptr, *ucol = nullptr;    // device, nnzL / nnzU + nbrows
 	int4 *lmeta = nullptr, *umeta = nullptr; // device, nbrows: {row, lptr[p], lptr[p+1], -} / {row, -, uptr[p], uptr[p+1]}
+	int4 *lhead = nullptr, *uhead = nullptr; // device, nbrows: column indices of a position's first 4 blocks (-1: none)
 	long nnz_lower = 0, nnz_dupper = 0;
 };
 
 // Arrays a single-launch pass reads instead of the natural-order ones (level-ordered copies)
 struct LevelView {
 	const int4 *meta = nullptr;
+	const int4 *head = nullptr;
 	const int *ptr = nullptr;
 	const int *bcolind = nullptr;
 	const double *vals = nullptr;
@@ -135,7 +137,7 @@ bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
                            hipStream_t s, const LevelView *view = nullptr);
 // kernels_levelw.hip (streaming exact triangular pass, column-major bs 4 / 8, level-ordered copies)
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          hipStream_t s);
+                          const int4 *head, hipStream_t s);
 void set_levelw_enabled(int on);
 void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals,

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void level_counts_kernel(const Pattern pat, co
 // column indices in level order + the descriptors of the two copies
 __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, const int *rows, const int *lptr,
                                                          const int *uptr, int *lcol, int *ucol, int4 *lmeta,
-                                                         int4 *umeta)
+                                                         int4 *umeta, int4 *lhead, int4 *uhead)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
 	if (k >= pat.nbrows)
@@ -496,6 +496,14 @@ __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, cons
 		ucol[u0 + (jj - dg)] = pat.bcolind[jj];
 	lmeta[k] = make_int4(row, l0, l0 + (dg - rp0), 0);
 	umeta[k] = make_int4(row, 0, u0, u0 + (rp1 - dg));
+	// the first four column indices of each copy, addressable from the position alone
+	int hl[4], hu[4];
+	for (int q = 0; q < 4; q++) {
+		hl[q] = (rp0 + q < dg) ? pat.bcolind[rp0 + q] : -1;
+		hu[q] = (dg + q < rp1) ? pat.bcolind[dg + q] : -1;
+	}
+	lhead[k] = make_int4(hl[0], hl[1], hl[2], hl[3]);
+	uhead[k] = make_int4(hu[0], hu[1], hu[2], hu[3]);
 }
 
 // values of the two triangles into level order: 16 lanes move one row, 8 bytes per lane and step
@@ -543,7 +551,7 @@ void free_level_schedule(LevelSchedule &ls)
 	if (ls.ctl)
 		(void)hipFree(ls.ctl);
 	for (void *q : {(void *)ls.lptr, (void *)ls.uptr, (void *)ls.lcol, (void *)ls.ucol, (void *)ls.lmeta,
-	                (void *)ls.umeta})
+	                (void *)ls.umeta, (void *)ls.lhead, (void *)ls.uhead})
 		if (q)
 			(void)hipFree(q);
 	ls = LevelSchedule();
@@ -692,7 +700,8 @@ bool launch_syncfree_sweep(const SweepArgs &a_, Part part, Post post, DSrc dsrc,
 		a.pat.bcolind = view->bcolind;
 		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
 		const bool ilu_upper = part == PART_UPPER && post == POST_D_SUB && dsrc == D_VALS_DIAG;
-		if ((ilu_lower || ilu_upper) && launch_syncfree_wide(a, ilu_upper, ls, view->ptr, view->bcolind, s))
+		if ((ilu_lower || ilu_upper) &&
+		    launch_syncfree_wide(a, ilu_upper, ls, view->ptr, view->bcolind, view->head, s))
 			return true;
 	}
 	if (!ls.built)
@@ -753,8 +762,10 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		ls.ucol = lvl_alloc<int>((size_t)ls.nnz_dupper);
 		ls.lmeta = lvl_alloc<int4>(n);
 		ls.umeta = lvl_alloc<int4>(n);
+		ls.lhead = lvl_alloc<int4>(n);
+		ls.uhead = lvl_alloc<int4>(n);
 		hipLaunchKernelGGL(level_cols_kernel, dim3(grid), dim3(256), 0, s, pat, ls.rows, ls.lptr, ls.uptr, ls.lcol,
-		                   ls.ucol, ls.lmeta, ls.umeta);
+		                   ls.ucol, ls.lmeta, ls.umeta, ls.lhead, ls.uhead);
 		BHIP_CHECK(hipGetLastError());
 		BHIP_CHECK(hipStreamSynchronize(s));
 		ls.storage_built = true;

@@ -2,9 +2,8 @@
 // blocks of size 4 and 8 (the layouts of kernels_sweepw.hip), on the LEVEL-ORDERED copies of the
 // factor's triangles (kernels_level.hip: build_level_storage / launch_level_permute_values).
 //
-// In level order consecutive positions are consecutive in memory, so the pass is the wide sweep kernel
-// again -- a workgroup owns RCHUNK consecutive positions, stages their block pointers, row numbers and
-// column indices in LDS, reads blocks as 16 bytes per lane, reduces on the VALU -- with two differences:
+// In level order consecutive positions are consecutive in memory, so the pass streams like the wide sweep
+// kernel -- blocks read as 16 bytes per lane, reduction on the VALU -- with these differences:
 //  * iterate entries a row depends on are POLLED (relaxed agent-scope atomic loads) until they stop
 //    being the "pending" pattern the output vector was filled with, and results are published with
 //    8-byte atomic stores; the block loads of a step are issued together with its first polls, so a
@@ -62,21 +61,19 @@ struct LWGeo {
 // UPPER = false: y_i = rhs_i - sum_{lower} L_ij y_j over the strictly-lower copy (ptr = lptr);
 // UPPER = true : z_i = D_i (rhs_i - sum_{upper} U_ij z_j) over the diagonal+upper copy, whose first
 //                block of every row is the (inverted) diagonal block.
-template <int BS, bool UPPER, int RCHUNK, int UNR>
+// A workgroup is UNR row steps, all requested at once.  Dependent chain of a row: {block pointers, row
+// number, its first four column indices (head)} -> {blocks, right-hand side, polled iterate entries} ->
+// result; no LDS, no workgroup barrier.
+template <int BS, bool UPPER, int UNR>
 __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *__restrict__ ptr,
-                                                  const int *__restrict__ cols, const int *__restrict__ rows,
-                                                  const int count, int *ctl)
+                                                  const int *__restrict__ cols, const int4 *__restrict__ head,
+                                                  const int *__restrict__ rows, const int count, int *ctl)
 {
 	using Ge = LWGeo<BS>;
 	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
-	constexpr int CAP = 8 * RCHUNK, KFIX = 2;
+	constexpr int KFIX = 2;
 	constexpr unsigned long long GMASK = G == 64 ? ~0ull : ((1ull << G) - 1ull);
 	static_assert(BS == 4 || BS == 8, "wide kernel: bs 4 or 8");
-	static_assert(RCHUNK % (RSTEP * UNR) == 0, "chunk must be a multiple of the unrolled step");
-
-	__shared__ int s_pt[RCHUNK + 1];
-	__shared__ int s_row[RCHUNK];
-	__shared__ int s_col[CAP];
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
@@ -86,187 +83,166 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 	const int gbase = lane & ~(G - 1);
 	const bool desc = a.descending != 0;
 
-	const long lin0 = (long)blockIdx.x * RCHUNK;
-	const int rc = (int)((count - lin0) < RCHUNK ? (count - lin0) : RCHUNK);
-	const int p0 = desc ? (int)(count - lin0 - rc) : (int)lin0;  // positions [p0, p0 + rc)
-
-	for (int k = tid; k <= rc; k += 256)
-		s_pt[k] = ptr[p0 + k];
-	for (int k = tid; k < rc; k += 256)
-		s_row[k] = rows[p0 + k];
-	__syncthreads();
-	const int jlo = __builtin_amdgcn_readfirstlane(s_pt[0]);
-	const int jhi = __builtin_amdgcn_readfirstlane(s_pt[rc]);
-	{
-		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
-		for (int k = tid; k < ncol; k += 256)
-			s_col[k] = cols[jlo + k];
+	int row[UNR], jbeg[UNR], jend[UNR];
+	int4 hd[UNR];
+	bool ok[UNR];
+#pragma unroll
+	for (int u = 0; u < UNR; u++) {
+		const long pos = ((long)blockIdx.x * UNR + u) * RSTEP + wave * RPW + g;  // position in sweep order
+		ok[u] = pos < count;
+		const int p = ok[u] ? (int)(desc ? count - 1 - pos : pos) : 0;
+		row[u] = rows[p];
+		jbeg[u] = ok[u] ? ptr[p] : 0;
+		jend[u] = ok[u] ? ptr[p + 1] : 0;
+		hd[u] = head[p];
 	}
-	__syncthreads();
 
-	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * (BS * BS));
+	const char *const vbase = reinterpret_cast<const char *>(a.vals);
 	const char *const xbase = reinterpret_cast<const char *>(a.xout);
 	const char *const rbase = reinterpret_cast<const char *>(a.rhs);
 	const char *const sbase = reinterpret_cast<const char *>(a.rscale);
 	char *const obase = reinterpret_cast<char *>(a.xout);
 
-	int spins = 0;
-	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
-		int row[UNR], jbeg[UNR], jend[UNR];
-		bool ok[UNR];
+	// blocks, right-hand side and the first polls of all UNR steps: one round trip
+	double2_t bv[UNR][KFIX];
+	double xv[UNR][KFIX];
+	unsigned xo[UNR][KFIX];
+	unsigned dep[UNR];
+	double2_t r2[UNR];
 #pragma unroll
-		for (int u = 0; u < UNR; u++) {
-			const int ls = (step0 + u) * RSTEP + wave * RPW + g;  // position in sweep order
-			ok[u] = ls < rc;
-			const int lr = ok[u] ? (desc ? rc - 1 - ls : ls) : 0;
-			row[u] = s_row[lr];
-			jbeg[u] = ok[u] ? s_pt[lr] : 0;
-			jend[u] = ok[u] ? s_pt[lr + 1] : 0;
+	for (int u = 0; u < UNR; u++) {
+		dep[u] = 0u;
+#pragma unroll
+		for (int k = 0; k < KFIX; k++) {
+			const int jj = jbeg[u] + slot + k * NB;
+			bv[u][k].x = 0.0;
+			bv[u][k].y = 0.0;
+			xv[u][k] = 0.0;
+			xo[u][k] = 0u;
+			if (jj < jend[u]) {
+				bv[u][k] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(
+				    vbase + ((long)jj * Ge::BLKBYTES + 16 * q)));
+				if (!(UPPER && jj == jbeg[u])) {  // the diagonal block multiplies no iterate entry
+					const int col = (k == 0) ? (slot == 0 ? hd[u].x : hd[u].y) : (slot == 0 ? hd[u].z : hd[u].w);
+					xo[u][k] = (unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c;
+					xv[u][k] = sfw_load(xbase + xo[u][k]);
+					if (sfw_pending(xv[u][k]))
+						dep[u] |= 1u << k;
+				}
+			}
 		}
+		r2[u].x = r2[u].y = 0.0;
+		if (ok[u]) {
+			r2[u] = *reinterpret_cast<const double2_t *>(
+			    rbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+			if (a.rscale) {
+				const double2_t s2 = *reinterpret_cast<const double2_t *>(
+				    sbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+				r2[u].x *= s2.x;
+				r2[u].y *= s2.y;
+			}
+		}
+	}
+	// rows longer than KFIX * NB blocks: the remainder is fetched (and polled) when the row commits
 
-		// blocks, right-hand side and the first polls of all UNR steps: one round trip
-		double2_t bv[UNR][KFIX];
-		double xv[UNR][KFIX];
-		unsigned xo[UNR][KFIX];
-		unsigned dep[UNR];
-		double2_t r2[UNR];
+	bool done[UNR];
+#pragma unroll
+	for (int u = 0; u < UNR; u++)
+		done[u] = !ok[u];
+	int spins = 0;
+	for (;;) {
+		bool alldone = true;
 #pragma unroll
 		for (int u = 0; u < UNR; u++) {
-			dep[u] = 0u;
+			if (__builtin_amdgcn_ballot_w64(!done[u]) == 0ull)
+				continue;
 #pragma unroll
 			for (int k = 0; k < KFIX; k++) {
-				const int jj = jbeg[u] + slot + k * NB;
-				bv[u][k].x = 0.0;
-				bv[u][k].y = 0.0;
-				xv[u][k] = 0.0;
-				xo[u][k] = 0u;
-				if (jj < jend[u]) {
-					bv[u][k] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(
-					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
-					if (!(UPPER && jj == jbeg[u])) {  // the diagonal block multiplies no iterate entry
-						const int cidx = jj - jlo;
-						const int col = (cidx < CAP) ? s_col[cidx] : cols[jj];
-						xo[u][k] = (unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c;
-						xv[u][k] = sfw_load(xbase + xo[u][k]);
-						if (sfw_pending(xv[u][k]))
-							dep[u] |= 1u << k;
+				if (dep[u] & (1u << k)) {
+					const double v = sfw_load(xbase + xo[u][k]);
+					if (!sfw_pending(v)) {
+						xv[u][k] = v;
+						dep[u] &= ~(1u << k);
 					}
 				}
 			}
-			r2[u].x = r2[u].y = 0.0;
-			if (ok[u]) {
-				r2[u] = *reinterpret_cast<const double2_t *>(
-				    rbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
-				if (a.rscale) {
-					const double2_t s2 = *reinterpret_cast<const double2_t *>(
-					    sbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
-					r2[u].x *= s2.x;
-					r2[u].y *= s2.y;
-				}
-			}
-		}
-		// rows longer than KFIX * NB blocks: the remainder is fetched (and polled) when the row commits
-
-		bool done[UNR];
-#pragma unroll
-		for (int u = 0; u < UNR; u++)
-			done[u] = !ok[u];
-		for (;;) {
-			bool alldone = true;
-#pragma unroll
-			for (int u = 0; u < UNR; u++) {
-				if (__builtin_amdgcn_ballot_w64(!done[u]) == 0ull)
-					continue;
+			const unsigned long long rb = __builtin_amdgcn_ballot_w64(dep[u] == 0u);
+			bool gready = ((rb >> gbase) & GMASK) == GMASK;
+			if (__builtin_amdgcn_ballot_w64(gready && !done[u]) != 0ull) {
+				double acc0 = 0.0, acc1 = 0.0, d0 = 0.0, d1 = 0.0;
 #pragma unroll
 				for (int k = 0; k < KFIX; k++) {
-					if (dep[u] & (1u << k)) {
-						const double v = sfw_load(xbase + xo[u][k]);
-						if (!sfw_pending(v)) {
-							xv[u][k] = v;
-							dep[u] &= ~(1u << k);
-						}
-					}
-				}
-				const unsigned long long rb = __builtin_amdgcn_ballot_w64(dep[u] == 0u);
-				bool gready = ((rb >> gbase) & GMASK) == GMASK;
-				if (__builtin_amdgcn_ballot_w64(gready && !done[u]) != 0ull) {
-					double acc0 = 0.0, acc1 = 0.0, d0 = 0.0, d1 = 0.0;
-#pragma unroll
-					for (int k = 0; k < KFIX; k++) {
-						if (UPPER && k == 0) {
-							const bool isd = (slot == 0);  // item 0 of the row: its inverted diagonal block
-							d0 = isd ? bv[u][0].x : 0.0;
-							d1 = isd ? bv[u][0].y : 0.0;
-							acc0 += isd ? 0.0 : bv[u][0].x * (gready ? xv[u][0] : 0.0);
-							acc1 += isd ? 0.0 : bv[u][0].y * (gready ? xv[u][0] : 0.0);
-						} else {
-							acc0 += bv[u][k].x * (gready ? xv[u][k] : 0.0);
-							acc1 += bv[u][k].y * (gready ? xv[u][k] : 0.0);
-						}
-					}
-					// remainder of long rows: a committing group polls these entries to completion here; they
-					// belong to earlier positions, so this cannot wait on the own wave
-					bool tail_ok = true;
-					if (gready && !done[u]) {
-						for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
-							const double2_t v2 = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(
-							    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
-							const int cidx = jj - jlo;
-							const int col = (cidx < CAP) ? s_col[cidx] : cols[jj];
-							const double xc = sfw_load(xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
-							if (sfw_pending(xc))
-								tail_ok = false;
-							acc0 += v2.x * xc;
-							acc1 += v2.y * xc;
-						}
-					}
-					// a group whose tail is not complete yet retries the whole row in a later round
-					const unsigned long long tb = __builtin_amdgcn_ballot_w64(tail_ok);
-					gready = gready && (((tb >> gbase) & GMASK) == GMASK);
-					acc0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc0);
-					acc1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc1);
-					double o0, o1;
-					if (!UPPER) {
-						o0 = r2[u].x - acc0;
-						o1 = r2[u].y - acc1;
+					if (UPPER && k == 0) {
+						const bool isd = (slot == 0);  // item 0 of the row: its inverted diagonal block
+						d0 = isd ? bv[u][0].x : 0.0;
+						d1 = isd ? bv[u][0].y : 0.0;
+						acc0 += isd ? 0.0 : bv[u][0].x * (gready ? xv[u][0] : 0.0);
+						acc1 += isd ? 0.0 : bv[u][0].y * (gready ? xv[u][0] : 0.0);
 					} else {
-						const double w0 = r2[u].x - acc0, w1 = r2[u].y - acc1;
-						double wc;
-						if (BS == 4) {
-							const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
-							const double a10 = dpp_mov<0x55>(w0), a11 = dpp_mov<0x55>(w1);  // quad_perm [1,1,1,1]
-							const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
-							const double s0 = b2 ? a10 : a00, s1 = b2 ? a11 : a01;
-							wc = b1 ? s1 : s0;
-						} else {
-							const int src = (lane & ~(HB - 1)) | (c >> 1);
-							const double t0 = __shfl(w0, src, 64), t1 = __shfl(w1, src, 64);
-							wc = (c & 1) ? t1 : t0;
-						}
-						o0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
-						o1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
+						acc0 += bv[u][k].x * (gready ? xv[u][k] : 0.0);
+						acc1 += bv[u][k].y * (gready ? xv[u][k] : 0.0);
 					}
-					if (!done[u] && gready && slot == 0 && q < HB) {
-						char *const dst = obase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
-						sfw_store(dst, o0);
-						sfw_store(dst + 8, o1);
-					}
-					done[u] = done[u] || gready;
 				}
-				if (!done[u])
-					alldone = false;
+				// remainder of long rows: a committing group polls these entries here; they belong to earlier
+				// positions, and a group whose tail is not complete yet retries the whole row in a later round
+				bool tail_ok = true;
+				if (gready && !done[u]) {
+					for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
+						const double2_t v2 = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(
+						    vbase + ((long)jj * Ge::BLKBYTES + 16 * q)));
+						const int col = cols[jj];
+						const double xc = sfw_load(xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+						if (sfw_pending(xc))
+							tail_ok = false;
+						acc0 += v2.x * xc;
+						acc1 += v2.y * xc;
+					}
+				}
+				const unsigned long long tb = __builtin_amdgcn_ballot_w64(tail_ok);
+				gready = gready && (((tb >> gbase) & GMASK) == GMASK);
+				acc0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc0);
+				acc1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc1);
+				double o0, o1;
+				if (!UPPER) {
+					o0 = r2[u].x - acc0;
+					o1 = r2[u].y - acc1;
+				} else {
+					const double w0 = r2[u].x - acc0, w1 = r2[u].y - acc1;
+					double wc;
+					if (BS == 4) {
+						const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
+						const double a10 = dpp_mov<0x55>(w0), a11 = dpp_mov<0x55>(w1);  // quad_perm [1,1,1,1]
+						const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
+						const double s0 = b2 ? a10 : a00, s1 = b2 ? a11 : a01;
+						wc = b1 ? s1 : s0;
+					} else {
+						const int src = (lane & ~(HB - 1)) | (c >> 1);
+						const double t0 = __shfl(w0, src, 64), t1 = __shfl(w1, src, 64);
+						wc = (c & 1) ? t1 : t0;
+					}
+					o0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
+					o1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
+				}
+				if (!done[u] && gready && slot == 0 && q < HB) {
+					char *const dst = obase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
+					sfw_store(dst, o0);
+					sfw_store(dst + 8, o1);
+				}
+				done[u] = done[u] || gready;
 			}
-			if (__builtin_amdgcn_ballot_w64(!alldone) == 0ull)
-				break;
-			spins++;
-			if (spins > SFW_SPIN_LIMIT ||
-			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-				if (lane == 0)
-					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				return;
-			}
-			__builtin_amdgcn_s_sleep(1);
+			if (!done[u])
+				alldone = false;
 		}
+		if (__builtin_amdgcn_ballot_w64(!alldone) == 0ull)
+			return;
+		spins++;
+		if (spins > SFW_SPIN_LIMIT ||
+		    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(1);
 	}
 }
 
@@ -285,7 +261,7 @@ void set_levelw_enabled(int on)
 // have been filled with the pending pattern.  Returns false when this kernel does not cover the case
 // (caller uses the general single-launch kernel).  The abort flag ls.ctl[1] is checked by the caller.
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          hipStream_t s)
+                          const int4 *head, hipStream_t s)
 {
 	const int bs = a.pat.bs;
 	if (!g_levelw_enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || ls.count == 0)
@@ -298,24 +274,25 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 	// last row of a level finished 8 (32) round trips late and every level paid for it (21.7 ms instead of
 	// 7.2 ms per exact apply at 256^3).  One step per wave keeps 8 waves per SIMD resident.
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
-#define BHIP_LW(B, UP, RC, U)                                                                               \
-	{                                                                                                       \
-		const unsigned grid = (unsigned)(((long)ls.count + RC - 1) / RC);                                   \
-		hipLaunchKernelGGL((sfw_kernel<B, UP, RC, U>), dim3(grid), dim3(256), 0, s, a, ptr, cols, ls.rows,  \
-		                   ls.count, ls.ctl);                                                               \
+#define BHIP_LW(B, UP, U)                                                                                  \
+	{                                                                                                      \
+		constexpr int RC = LWGeo<B>::RSTEP * U;                                                            \
+		const unsigned grid = (unsigned)(((long)ls.count + RC - 1) / RC);                                  \
+		hipLaunchKernelGGL((sfw_kernel<B, UP, U>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, ls.rows, \
+		                   ls.count, ls.ctl);                                                              \
 	}
 	const int v = g_levelw_variant;
 	if (bs == 4) {
 		if (upper) {
-			if (v == 1) BHIP_LW(4, true, 32, 2) else BHIP_LW(4, true, 16, 1)
+			if (v == 1) BHIP_LW(4, true, 2) else BHIP_LW(4, true, 1)
 		} else {
-			if (v == 1) BHIP_LW(4, false, 32, 2) else BHIP_LW(4, false, 16, 1)
+			if (v == 1) BHIP_LW(4, false, 2) else BHIP_LW(4, false, 1)
 		}
 	} else {
 		if (upper) {
-			if (v == 1) BHIP_LW(8, true, 8, 2) else BHIP_LW(8, true, 4, 1)
+			if (v == 1) BHIP_LW(8, true, 2) else BHIP_LW(8, true, 1)
 		} else {
-			if (v == 1) BHIP_LW(8, false, 8, 2) else BHIP_LW(8, false, 4, 1)
+			if (v == 1) BHIP_LW(8, false, 2) else BHIP_LW(8, false, 1)
 		}
 	}
 #undef BHIP_LW
