@@ -1088,7 +1088,9 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 int blasted_hip_set_tuning(const char *spec)
 {
 	return guarded([&] {
-		if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
+		if (spec && std::strncmp(spec, "sfonestep=", 10) == 0)
+			set_syncfree_one_step(spec[10] != '0');
+		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
 		else if (spec && std::strncmp(spec, "levelstore=", 11) == 0)
 			g_level_store = spec[11] != '0';

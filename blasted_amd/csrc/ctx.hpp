@@ -139,6 +139,7 @@ bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
                           const int4 *head, hipStream_t s);
 void set_levelw_enabled(int on);
+void set_syncfree_one_step(int on);
 void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals,
                                  double *lvals, double *uvals, hipStream_t s);

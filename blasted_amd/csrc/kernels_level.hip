@@ -279,7 +279,7 @@ __device__ __forceinline__ bool sf_pending(double v)
 // KF = block passes held in registers: every row part must fit KF * NB blocks (checked by the launcher).
 template <int BS, bool RM, int PART, int POST, int DSRC, int KF, int ST>
 __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const int4 *__restrict__ meta,
-                                                       const int count, int *ctl)
+                                                       const int4 *__restrict__ head, const int count, int *ctl)
 {
 	using Ge = Geo<BS>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
@@ -297,15 +297,22 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 	const bool desc = a.descending != 0;
 	const long base = ((long)blockIdx.x * 4 + wave) * (ST * RPW);
 
-	int4 mt[ST];
+	// head (level-ordered copies only): the column indices of a row part's first four blocks, addressable
+	// from the position alone, so the polls of those blocks start together with the block loads
+	int4 mt[ST], hd[ST];
 	bool okk[ST];
 #pragma unroll
 	for (int st = 0; st < ST; st++) {
 		const long pos = base + st * RPW + g;
 		okk[st] = pos < count;
 		mt[st] = make_int4(0, 0, 0, 0);
-		if (okk[st])
-			mt[st] = meta[desc ? count - 1 - pos : pos];
+		hd[st] = make_int4(0, 0, 0, 0);
+		if (okk[st]) {
+			const long p = desc ? count - 1 - pos : pos;
+			mt[st] = meta[p];
+			if (head)
+				hd[st] = head[p];
+		}
 	}
 	// the rows' blocks and indices: independent of every other row, all in flight before any wait
 	double bv[ST][KF], xv[ST][KF], d[ST], rv[ST];
@@ -340,7 +347,12 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 				if (DIAG_RIDES && jj == dg) {
 					d[st] = (DSRC == D_VALS_DIAG) ? v : 1.0 / v;
 				} else {
-					const int col = a.pat.bcolind[jj];
+					const int idx = slot + k * NB;  // item number inside the row part (copies: jbeg is its start)
+					int col;
+					if (head && idx < 4)
+						col = idx == 0 ? hd[st].x : (idx == 1 ? hd[st].y : (idx == 2 ? hd[st].z : hd[st].w));
+					else
+						col = a.pat.bcolind[jj];
 					bv[st][k] = v;
 					xo[st][k] = col * BS + c;
 					if (PART == PART_OFFDIAG && (desc ? col < row : col > row))
@@ -419,8 +431,13 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 	}
 }
 
+// One row step per wave (8 waves per SIMD resident) instead of 4 / 2 prefetched steps: 1.8x faster at bs=5
+// and 7 on the Poisson pattern, equal on long rows; 0 = the prefetching variants (tuning).
+int g_sf_one_step = 1;
+
 template <int BS, bool RM, int PART, int POST, int DSRC>
-bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStream_t s, const int4 *meta)
+bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStream_t s, const int4 *meta,
+                  const int4 *head)
 {
 	constexpr int NB = Geo<BS>::NB, RPW = Geo<BS>::RPW;
 	const int passes = (need + NB - 1) / NB;
@@ -430,11 +447,16 @@ bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStre
 		const long grid = ((long)ls.count + per_wg - 1) / per_wg;                                           \
 		if (grid > 0)                                                                                       \
 			hipLaunchKernelGGL((sf_sweep_kernel<BS, RM, PART, POST, DSRC, K, STEPS>), dim3((unsigned)grid), \
-			                   dim3(256), 0, s, a, meta, ls.count, ls.ctl);                                 \
+			                   dim3(256), 0, s, a, meta, head, ls.count, ls.ctl);                           \
 		return true;                                                                                        \
 	}
-	BHIP_KF(4, 4)
-	BHIP_KF(8, 2)
+	if (g_sf_one_step) {
+		BHIP_KF(4, 1)
+		BHIP_KF(8, 1)
+	} else {
+		BHIP_KF(4, 4)
+		BHIP_KF(8, 2)
+	}
 	BHIP_KF(16, 1)
 #undef BHIP_KF
 	return false;
@@ -442,12 +464,12 @@ bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStre
 
 template <int BS, bool RM>
 bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls, hipStream_t s,
-                     const int4 *meta)
+                     const int4 *meta, const int4 *head)
 {
 	const int lo = ls.max_lower, up = ls.max_upper;
 #define BHIP_CASE(P, Q, D, NEED)                                       \
 	if (part == P && post == Q && dsrc == D)                           \
-		return sf_launch_kf<BS, RM, P, Q, D>(a, ls, NEED, s, meta);
+		return sf_launch_kf<BS, RM, P, Q, D>(a, ls, NEED, s, meta, head);
 	BHIP_CASE(PART_LOWER, POST_SUB, D_NONE, lo)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_VALS_DIAG, up + 1)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_RECIP_DIAG, up + 1)
@@ -460,11 +482,11 @@ bool sf_dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, const 
 
 template <int BS>
 bool sf_dispatch_layout(const SweepArgs &a, Part part, Post post, DSrc dsrc, const LevelSchedule &ls,
-                        hipStream_t s, const int4 *meta)
+                        hipStream_t s, const int4 *meta, const int4 *head)
 {
 	if (BS > 1 && a.pat.rowmajor)
-		return sf_dispatch_ops<BS, true>(a, part, post, dsrc, ls, s, meta);
-	return sf_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s, meta);
+		return sf_dispatch_ops<BS, true>(a, part, post, dsrc, ls, s, meta, head);
+	return sf_dispatch_ops<BS, false>(a, part, post, dsrc, ls, s, meta, head);
 }
 
 // level-ordered storage: per-position block counts of the two triangles
@@ -539,6 +561,11 @@ T *lvl_alloc(size_t count)
 }
 
 }  // namespace
+
+void set_syncfree_one_step(int on)
+{
+	g_sf_one_step = on;
+}
 
 void free_level_schedule(LevelSchedule &ls)
 {
@@ -693,9 +720,10 @@ bool launch_syncfree_sweep(const SweepArgs &a_, Part part, Post post, DSrc dsrc,
                            hipStream_t s, const LevelView *view)
 {
 	SweepArgs a = a_;
-	const int4 *meta = ls.meta;
+	const int4 *meta = ls.meta, *head = nullptr;
 	if (view) {  // level-ordered copies: contiguous stream
 		meta = view->meta;
+		head = view->head;
 		a.vals = view->vals;
 		a.pat.bcolind = view->bcolind;
 		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
@@ -711,13 +739,13 @@ bool launch_syncfree_sweep(const SweepArgs &a_, Part part, Post post, DSrc dsrc,
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 	bool ok = false;
 	switch (a.pat.bs) {
-	case 1: ok = sf_dispatch_layout<1>(a, part, post, dsrc, ls, s, meta); break;
-	case 2: ok = sf_dispatch_layout<2>(a, part, post, dsrc, ls, s, meta); break;
-	case 3: ok = sf_dispatch_layout<3>(a, part, post, dsrc, ls, s, meta); break;
-	case 4: ok = sf_dispatch_layout<4>(a, part, post, dsrc, ls, s, meta); break;
-	case 5: ok = sf_dispatch_layout<5>(a, part, post, dsrc, ls, s, meta); break;
-	case 7: ok = sf_dispatch_layout<7>(a, part, post, dsrc, ls, s, meta); break;
-	case 8: ok = sf_dispatch_layout<8>(a, part, post, dsrc, ls, s, meta); break;
+	case 1: ok = sf_dispatch_layout<1>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 2: ok = sf_dispatch_layout<2>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 3: ok = sf_dispatch_layout<3>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 4: ok = sf_dispatch_layout<4>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 5: ok = sf_dispatch_layout<5>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 7: ok = sf_dispatch_layout<7>(a, part, post, dsrc, ls, s, meta, head); break;
+	case 8: ok = sf_dispatch_layout<8>(a, part, post, dsrc, ls, s, meta, head); break;
 	default: BHIP_FAIL(BLASTED_HIP_ENOTIMPL, "block size not instantiated (1,2,3,4,5,7,8)");
 	}
 	BHIP_CHECK(hipGetLastError());

@@ -39,6 +39,9 @@ def main():
     print("ilu factor exact      %8.3f ms" % timed(lambda: p.ilu0_factorize(-1), 2))
     print("ilu factor ASYNC s=3  %8.3f ms" % timed(lambda: p.ilu0_factorize(3), 2))
     print("ilu apply  LEVEL      %8.3f ms" % timed(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z), 5), p.level_stats())
+    capi.set_tuning("sfonestep=0")
+    print("   sfonestep=0         %8.3f ms" % timed(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z), 5))
+    capi.set_tuning("sfonestep=1")
     if bs in (4, 8):
         for spec in ("levelwide=0", "levelstore=0", "level=launch"):
             capi.set_tuning(spec)
