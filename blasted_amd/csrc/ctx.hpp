@@ -91,7 +91,7 @@ struct LevelSchedule {
 	int *lptr = nullptr, *uptr = nullptr;    // device, nbrows + 1
 	int *lcol = nullptr, *ucol = nullptr;    // device, nnzL / nnzU + nbrows
 	int4 *lmeta = nullptr, *umeta = nullptr; // device, nbrows: {row, lptr[p], lptr[p+1], -} / {row, -, uptr[p], uptr[p+1]}
-	int4 *lhead = nullptr, *uhead = nullptr; // device, nbrows: column indices of a position's first 4 blocks (-1: none)
+	int4 *lhead = nullptr, *uhead = nullptr; // device, 2 * nbrows: column indices of a position's first 8 blocks (-1: none)
 	long nnz_lower = 0, nnz_dupper = 0;
 };
 

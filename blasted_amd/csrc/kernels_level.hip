@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 
 	// head (level-ordered copies only): the column indices of a row part's first four blocks, addressable
 	// from the position alone, so the polls of those blocks start together with the block loads
-	int4 mt[ST], hd[ST];
+	constexpr bool HEAD8 = KF * NB > 4;  // second half of the head only where a lane can reach it
+	int4 mt[ST], hd[ST], hd2[ST];
 	bool okk[ST];
 #pragma unroll
 	for (int st = 0; st < ST; st++) {
@@ -307,11 +308,15 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 		okk[st] = pos < count;
 		mt[st] = make_int4(0, 0, 0, 0);
 		hd[st] = make_int4(0, 0, 0, 0);
+		hd2[st] = make_int4(0, 0, 0, 0);
 		if (okk[st]) {
 			const long p = desc ? count - 1 - pos : pos;
 			mt[st] = meta[p];
-			if (head)
-				hd[st] = head[p];
+			if (head) {
+				hd[st] = head[2 * p];
+				if (HEAD8)
+					hd2[st] = head[2 * p + 1];
+			}
 		}
 	}
 	// the rows' blocks and indices: independent of every other row, all in flight before any wait
@@ -351,6 +356,8 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 					int col;
 					if (head && idx < 4)
 						col = idx == 0 ? hd[st].x : (idx == 1 ? hd[st].y : (idx == 2 ? hd[st].z : hd[st].w));
+					else if (HEAD8 && head && idx < 8)
+						col = idx == 4 ? hd2[st].x : (idx == 5 ? hd2[st].y : (idx == 6 ? hd2[st].z : hd2[st].w));
 					else
 						col = a.pat.bcolind[jj];
 					bv[st][k] = v;
@@ -518,14 +525,16 @@ __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, cons
 		ucol[u0 + (jj - dg)] = pat.bcolind[jj];
 	lmeta[k] = make_int4(row, l0, l0 + (dg - rp0), 0);
 	umeta[k] = make_int4(row, 0, u0, u0 + (rp1 - dg));
-	// the first four column indices of each copy, addressable from the position alone
-	int hl[4], hu[4];
-	for (int q = 0; q < 4; q++) {
+	// the first eight column indices of each copy, addressable from the position alone (two int4 each)
+	int hl[8], hu[8];
+	for (int q = 0; q < 8; q++) {
 		hl[q] = (rp0 + q < dg) ? pat.bcolind[rp0 + q] : -1;
 		hu[q] = (dg + q < rp1) ? pat.bcolind[dg + q] : -1;
 	}
-	lhead[k] = make_int4(hl[0], hl[1], hl[2], hl[3]);
-	uhead[k] = make_int4(hu[0], hu[1], hu[2], hu[3]);
+	lhead[2 * k] = make_int4(hl[0], hl[1], hl[2], hl[3]);
+	lhead[2 * k + 1] = make_int4(hl[4], hl[5], hl[6], hl[7]);
+	uhead[2 * k] = make_int4(hu[0], hu[1], hu[2], hu[3]);
+	uhead[2 * k + 1] = make_int4(hu[4], hu[5], hu[6], hu[7]);
 }
 
 // values of the two triangles into level order: 16 lanes move one row, 8 bytes per lane and step
@@ -790,8 +799,8 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		ls.ucol = lvl_alloc<int>((size_t)ls.nnz_dupper);
 		ls.lmeta = lvl_alloc<int4>(n);
 		ls.umeta = lvl_alloc<int4>(n);
-		ls.lhead = lvl_alloc<int4>(n);
-		ls.uhead = lvl_alloc<int4>(n);
+		ls.lhead = lvl_alloc<int4>(2 * (size_t)n);
+		ls.uhead = lvl_alloc<int4>(2 * (size_t)n);
 		hipLaunchKernelGGL(level_cols_kernel, dim3(grid), dim3(256), 0, s, pat, ls.rows, ls.lptr, ls.uptr, ls.lcol,
 		                   ls.ucol, ls.lmeta, ls.umeta, ls.lhead, ls.uhead);
 		BHIP_CHECK(hipGetLastError());

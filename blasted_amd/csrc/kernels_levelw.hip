@@ -1,6 +1,6 @@
 // kernels_levelw.hip -- the streaming form of the one-launch exact triangular solve for column-major
-// blocks of size 4 and 8 (the layouts of kernels_sweepw.hip), on the LEVEL-ORDERED copies of the
-// factor's triangles (kernels_level.hip: build_level_storage / launch_level_permute_values).
+// blocks of size 4 and 8 (the lane layout of kernels_sweepw.hip) and 3, 5, 7 (that of
+// kernels_sweepodd.hip), on the LEVEL-ORDERED copies of the factor's triangles (kernels_level.hip: build_level_storage / launch_level_permute_values).
 //
 // In level order consecutive positions are consecutive in memory, so the pass streams like the wide sweep
 // kernel -- blocks read as 16 bytes per lane, reduction on the VALU -- with these differences:
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 		row[u] = rows[p];
 		jbeg[u] = ok[u] ? ptr[p] : 0;
 		jend[u] = ok[u] ? ptr[p + 1] : 0;
-		hd[u] = head[p];
+		hd[u] = head[2 * p];  // the first four of the eight head entries
 	}
 
 	const char *const vbase = reinterpret_cast<const char *>(a.vals);
@@ -246,6 +246,174 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 	}
 }
 
+// ---- odd block sizes 3, 5, 7 (the lane layout of kernels_sweepodd.hip) -----------------------------------
+// G = 8 / 16 / 32 lanes per row, L = (bs*bs+1)/2 of them hold a block as 16 bytes per lane, the stride-bs
+// reduction goes through a wave-private LDS tile.  One row step per wave, up to eight blocks of a row
+// part requested at once (their column indices come from the head); longer rows finish at commit time.
+typedef double2_t d2u_t __attribute__((aligned(8)));  // 16-byte access at 8-byte alignment
+
+template <int BS, bool UPPER>
+__global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int *__restrict__ ptr,
+                                                    const int *__restrict__ cols, const int4 *__restrict__ head,
+                                                    const int *__restrict__ rows, const int count, int *ctl)
+{
+	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
+	constexpr int BS2 = BS * BS, L = (BS2 + 1) / 2;
+	constexpr int G = BS == 3 ? 8 : (BS == 5 ? 16 : 32);
+	constexpr int RPW = 64 / G, RSTEP = 4 * RPW, KFIX = 8;
+	constexpr int BLKBYTES = BS2 * 8, ROWBYTES = BS * 8;
+	constexpr unsigned long long GMASK = (1ull << G) - 1ull;
+
+	__shared__ double s_acc[4][RPW][BS2 + 1];
+	__shared__ double s_w[4][RPW][BS + 1];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int g = lane / G, t = lane % G;
+	const int gbase = lane & ~(G - 1);
+	const bool actA = t < L - 1, actB = t < L;
+	const int eA = actA ? 2 * t : BS2 - 2, eB = actA ? 2 * t + 1 : BS2 - 1;
+	const long boff = actA ? 16 * t : 8 * (BS2 - 2);
+	const int cA = (eA / BS) < BS ? eA / BS : BS - 1, cB = (eB / BS) < BS ? eB / BS : BS - 1;
+	const int cx = cA < BS - 2 ? cA : BS - 2;
+	const bool hiA = cA != cx, hiB = cB != cx;
+	const bool desc = a.descending != 0;
+
+	const long pos = (long)blockIdx.x * RSTEP + wave * RPW + g;  // position in sweep order
+	const bool ok = pos < count;
+	const int p = ok ? (int)(desc ? count - 1 - pos : pos) : 0;
+	const int row = rows[p];
+	const int jbeg = ok ? ptr[p] : 0, jend = ok ? ptr[p + 1] : 0;
+	const int4 h0 = head[2 * p], h1 = head[2 * p + 1];
+
+	const char *const vbase = reinterpret_cast<const char *>(a.vals);
+	const char *const xbase = reinterpret_cast<const char *>(a.xout);
+	char *const obase = reinterpret_cast<char *>(a.xout);
+	double *const tile = &s_acc[wave][g][0];
+	double *const wvec = &s_w[wave][g][0];
+
+	d2u_t bv[KFIX];
+	double xa[KFIX], xb[KFIX];  // x_cx, x_cx+1 of each block's column segment
+	unsigned xo[KFIX];
+	unsigned dep = 0u;
+#pragma unroll
+	for (int k = 0; k < KFIX; k++) {
+		const int jj = jbeg + k;
+		bv[k].x = bv[k].y = 0.0;
+		xa[k] = xb[k] = 0.0;
+		xo[k] = 0u;
+		if (jj < jend && actB) {
+			bv[k] = __builtin_nontemporal_load(reinterpret_cast<const d2u_t *>(vbase + ((long)jj * BLKBYTES + boff)));
+			if (!(UPPER && k == 0)) {  // item 0 of the upper copy is the diagonal block
+				const int col = k == 0 ? h0.x : (k == 1 ? h0.y : (k == 2 ? h0.z : (k == 3 ? h0.w : (k == 4 ? h1.x : (k == 5 ? h1.y : (k == 6 ? h1.z : h1.w))))));
+				xo[k] = (unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx;
+				xa[k] = sfw_load(xbase + xo[k]);
+				xb[k] = sfw_load(xbase + xo[k] + 8);
+				if (sfw_pending(xa[k]) || sfw_pending(xb[k]))
+					dep |= 1u << k;
+			}
+		}
+	}
+	double rv = 0.0;
+	if (ok && t < BS) {
+		rv = a.rhs[(long)row * BS + t];
+		if (a.rscale)
+			rv *= a.rscale[(long)row * BS + t];
+	}
+
+	bool done = !ok;
+	int spins = 0;
+	for (;;) {
+#pragma unroll
+		for (int k = 0; k < KFIX; k++) {
+			if (dep & (1u << k)) {
+				const double va = sfw_load(xbase + xo[k]), vb = sfw_load(xbase + xo[k] + 8);
+				if (!sfw_pending(va) && !sfw_pending(vb)) {
+					xa[k] = va;
+					xb[k] = vb;
+					dep &= ~(1u << k);
+				}
+			}
+		}
+		const unsigned long long rb = __builtin_amdgcn_ballot_w64(dep == 0u);
+		bool gready = ((rb >> gbase) & GMASK) == GMASK;
+		if (__builtin_amdgcn_ballot_w64(gready && !done) != 0ull) {
+			double accA = 0.0, accB = 0.0;
+			d2u_t dv;
+			dv.x = dv.y = 0.0;
+#pragma unroll
+			for (int k = 0; k < KFIX; k++) {
+				if (UPPER && k == 0) {
+					dv = bv[0];
+				} else if (gready) {
+					accA += bv[k].x * (hiA ? xb[k] : xa[k]);
+					accB += bv[k].y * (hiB ? xb[k] : xa[k]);
+				}
+			}
+			bool tail_ok = true;
+			if (gready && !done && actB) {
+				for (int jj = jbeg + KFIX; jj < jend; jj++) {
+					const d2u_t v2 =
+					    __builtin_nontemporal_load(reinterpret_cast<const d2u_t *>(vbase + ((long)jj * BLKBYTES + boff)));
+					const unsigned o = (unsigned)cols[jj] * (unsigned)ROWBYTES + 8u * (unsigned)cx;
+					const double va = sfw_load(xbase + o), vb = sfw_load(xbase + o + 8);
+					if (sfw_pending(va) || sfw_pending(vb))
+						tail_ok = false;
+					accA += v2.x * (hiA ? vb : va);
+					accB += v2.y * (hiB ? vb : va);
+				}
+			}
+			const unsigned long long tb = __builtin_amdgcn_ballot_w64(tail_ok);
+			gready = gready && (((tb >> gbase) & GMASK) == GMASK);
+			if (actA)
+				tile[eA] = accA;
+			if (actB)
+				tile[eB] = accB;
+			__builtin_amdgcn_wave_barrier();
+			double sum = 0.0;
+			if (t < BS) {
+#pragma unroll
+				for (int cc = 0; cc < BS; cc++)
+					sum += tile[cc * BS + t];
+			}
+			__builtin_amdgcn_wave_barrier();
+			double out = rv - sum;
+			if (UPPER) {
+				if (t < BS)
+					wvec[t] = out;
+				__builtin_amdgcn_wave_barrier();
+				const double wA = wvec[cA], wB = wvec[cB];
+				if (actA)
+					tile[eA] = dv.x * wA;
+				if (actB)
+					tile[eB] = dv.y * wB;
+				__builtin_amdgcn_wave_barrier();
+				double pr = 0.0;
+				if (t < BS) {
+#pragma unroll
+					for (int cc = 0; cc < BS; cc++)
+						pr += tile[cc * BS + t];
+				}
+				__builtin_amdgcn_wave_barrier();
+				out = pr;
+			}
+			if (!done && gready && t < BS)
+				sfw_store(obase + ((unsigned)row * (unsigned)ROWBYTES + 8u * (unsigned)t), out);
+			done = done || gready;
+		}
+		if (__builtin_amdgcn_ballot_w64(!done) == 0ull)
+			return;
+		spins++;
+		if (spins > SFW_SPIN_LIMIT ||
+		    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+
 int g_levelw_enabled = 1;
 int g_levelw_variant = 0;  // 0: one row step per wave (default), 1: two
 
@@ -264,7 +432,29 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
                           const int4 *head, hipStream_t s)
 {
 	const int bs = a.pat.bs;
-	if (!g_levelw_enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || ls.count == 0)
+	if (!g_levelw_enabled || a.pat.rowmajor || ls.count == 0)
+		return false;
+	if (bs == 3 || bs == 5 || bs == 7) {
+		BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+#define BHIP_LO(B, UP)                                                                                          \
+	{                                                                                                           \
+		constexpr int RS = 4 * (64 / (B == 3 ? 8 : (B == 5 ? 16 : 32)));                                        \
+		const unsigned grid = (unsigned)(((long)ls.count + RS - 1) / RS);                                       \
+		hipLaunchKernelGGL((sfodd_kernel<B, UP>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, ls.rows,     \
+		                   ls.count, ls.ctl);                                                                   \
+	}
+		if (bs == 3) {
+			if (upper) BHIP_LO(3, true) else BHIP_LO(3, false)
+		} else if (bs == 5) {
+			if (upper) BHIP_LO(5, true) else BHIP_LO(5, false)
+		} else {
+			if (upper) BHIP_LO(7, true) else BHIP_LO(7, false)
+		}
+#undef BHIP_LO
+		BHIP_CHECK(hipGetLastError());
+		return true;
+	}
+	if (bs != 4 && bs != 8)
 		return false;
 	auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
 	if (misaligned(a.vals) || misaligned(a.rhs) || misaligned(a.rscale) || misaligned(a.xout))
