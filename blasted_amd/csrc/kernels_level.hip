@@ -438,8 +438,9 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 	}
 }
 
-// One row step per wave (8 waves per SIMD resident) instead of 4 / 2 prefetched steps: 1.8x faster at bs=5
-// and 7 on the Poisson pattern, equal on long rows; 0 = the prefetching variants (tuning).
+// Short row parts (up to 4 block passes): one row step per wave (8 waves per SIMD resident) instead of 4
+// prefetched steps -- 1.7-1.8x faster exact solves on the Poisson pattern at every block size; 0 = the
+// prefetching variant (tuning).
 int g_sf_one_step = 1;
 
 template <int BS, bool RM, int PART, int POST, int DSRC>
@@ -459,11 +460,10 @@ bool sf_launch_kf(const SweepArgs &a, const LevelSchedule &ls, int need, hipStre
 	}
 	if (g_sf_one_step) {
 		BHIP_KF(4, 1)
-		BHIP_KF(8, 1)
 	} else {
 		BHIP_KF(4, 4)
-		BHIP_KF(8, 2)
 	}
+	BHIP_KF(8, 2)  // relaxation passes at 256^3: 15.4 ms with two steps per wave, 18.2 ms with one
 	BHIP_KF(16, 1)
 #undef BHIP_KF
 	return false;
