@@ -228,6 +228,24 @@ def main():
                          "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
                          "other_ms_per_step": tm["other_ms"] / args.steps},
         }
+        if world == 1 and args.op == "ilu_apply":
+            # side figure, never `value`: the exact (level-scheduled) solve the sweeps approximate
+            def _t(fn, reps=5):
+                fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / reps * 1e3
+            try:
+                ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
+                st = p.level_stats()
+                out["exact_apply"] = {"ms": ex, "levels": st["levels"], "syncfree_aborts": st["syncfree_aborts"],
+                                      "note": "one exact L and U solve (mode LEVEL), beside ms_per_step for %d+%d "
+                                              "asynchronous sweeps" % (s, s)}
+            except Exception as e:
+                out["exact_apply"] = {"ms": None, "note": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.op, args.cpu_sample_n, bs, s, unit_bytes, units_per_step)
