@@ -140,6 +140,7 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
                           const int4 *head, hipStream_t s);
 void set_levelw_enabled(int on);
 void set_syncfree_one_step(int on);
+void build_natural_storage(const Pattern &pat, LevelSchedule &ns, hipStream_t s);
 void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals,
                                  double *lvals, double *uvals, hipStream_t s);
@@ -210,6 +211,9 @@ struct blasted_hip_prec_s {
 	bhip::LevelSchedule levels;
 	double *lfac = nullptr, *ufac = nullptr;  // level-ordered copies of the factor's triangles
 	bool lfac_valid = false;
+	bhip::LevelSchedule natstore;               // natural-order compact triangle storage (pattern part)
+	double *nlfac = nullptr, *nufac = nullptr;  // ... and the factor's values in it
+	bool nfac_valid = false;
 
 	bhip::Timing timing;
 

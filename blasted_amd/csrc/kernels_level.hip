@@ -817,6 +817,21 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 			(void)hipFree(q);
 }
 
+// The same compact two-triangle storage in NATURAL row order (rows = identity): the asynchronous sweeps
+// then stream exactly the blocks and indices of their triangle.
+void build_natural_storage(const Pattern &pat, LevelSchedule &ns, hipStream_t s)
+{
+	if (ns.storage_built)
+		return;
+	const int n = pat.nbrows;
+	ns.rows = lvl_alloc<int>((size_t)(n ? n : 1));
+	if (n)
+		hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ns.rows, n);
+	ns.count = n;
+	ns.built = true;
+	build_level_storage(pat, ns, s);
+}
+
 // Values of both triangles into level order (after every factorisation that is applied exactly).
 void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals, double *lvals,
                                  double *uvals, hipStream_t s)

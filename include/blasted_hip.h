@@ -176,6 +176,9 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
  * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":
  * exact triangular solves read level-ordered copies of the factor's triangles (one extra copy of the
  * factor, permuted once per factorisation) or the factor in place (environment: BLASTED_HIP_LEVELSTORE);
+ * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
+ * factor's triangles (one more copy of the factor, one copy pass per factorisation) or the factor in
+ * place (environment: BLASTED_HIP_COMPACT).
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
  * lets a wave of that kernel prefetch several row steps instead of one. */
 int blasted_hip_set_tuning(const char *spec);

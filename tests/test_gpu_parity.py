@@ -36,6 +36,15 @@ def make_prec(m):
     return p
 
 
+@pytest.fixture(params=["compact", "inplace"])
+def factor_storage(request):
+    """The asynchronous ILU sweeps read compact copies of the factor's triangles (default) or the factor
+    in place: the tests of the apply run with both."""
+    capi.set_tuning("compact=" + ("1" if request.param == "compact" else "0"))
+    yield request.param
+    capi.set_tuning("compact=1")
+
+
 def matrices(golden):
     return {
         "2dcyl1_bs4_col": lambda: mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False),
@@ -210,7 +219,7 @@ def load_exact_factor(p, m, usescale=False):
 
 @pytest.mark.parametrize("case", ALL)
 @pytest.mark.parametrize("init", [capi.INIT_A_ZERO, capi.INIT_A_JACOBI])
-def test_ilu_apply_sync_sweeps_match_oracle(golden, case, init):
+def test_ilu_apply_sync_sweeps_match_oracle(golden, case, init, factor_storage):
     m = matrices(golden)[case]()
     n = m["nbrows"] * m["bs"]
     r = W.rhs_vector(n)
@@ -229,7 +238,7 @@ def test_ilu_apply_sync_sweeps_match_oracle(golden, case, init):
 
 @pytest.mark.parametrize("case", ALL)
 @pytest.mark.parametrize("usescale", [False, True])
-def test_ilu_apply_async_converges_to_exact(golden, case, usescale):
+def test_ilu_apply_async_converges_to_exact(golden, case, usescale, factor_storage):
     m = matrices(golden)[case]()
     if usescale and case.startswith("random"):
         pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
@@ -363,7 +372,7 @@ def test_solve_known_answer_on_gpu(golden, mat, bs, rowmajor, prec):
 
 # ---------------------------------------------------------------------------- edge cases
 
-def test_tiny_and_ragged_matrices():
+def test_tiny_and_ragged_matrices(factor_storage):
     # 1 block-row; rows with empty lower / upper parts; row count not a multiple of the rows per workgroup
     for nb, bs in ((1, 4), (2, 5), (3, 1), (17, 4), (65, 8), (5, 3), (129, 7), (33, 3), (131, 5), (9, 2)):
         m = W.random_bsr(nb, bs, avg_offdiag=2, seed=nb)
