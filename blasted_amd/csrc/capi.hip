@@ -1152,6 +1152,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepodd_enabled(spec[9] != '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
+		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)
+			set_factorodd_enabled(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)

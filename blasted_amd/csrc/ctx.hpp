@@ -150,6 +150,9 @@ void set_factor4_enabled(int on);
 // kernels_factor8.hip (bs=8 column-major factorisation sweep on the matrix core)
 bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s);
 void set_factor8_enabled(int on);
+// kernels_factorodd.hip (bs=5/7 column-major factorisation sweep in the 16-byte pair layout)
+bool launch_factorodd(const FactorArgs &a, double *dinv_scratch, hipStream_t s);
+void set_factorodd_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);

@@ -502,6 +502,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 		return;
 	if (launch_factor8(a, a.dinv_scratch, s))
 		return;
+	if (launch_factorodd(a, a.dinv_scratch, s))
+		return;
 	if (a.pat.bs >= 5 && a.dinv_scratch)
 		launch_invert_diag_blocks(a.pat, a.in, 1, a.dinv_scratch, 0, s);
 	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
