@@ -238,17 +238,19 @@ __global__ __launch_bounds__(256) void invert_blocks_kernel(const Pattern pat, c
 template <int BS, bool RM>
 __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat, const double *src,
                                                                const int src_by_diag, double *dst,
-                                                               const int dst_by_diag)
+                                                               const int dst_by_diag, const int *rows,
+                                                               const int nlist)
 {
 	constexpr int BS2 = BS * BS, LD = BS2 + 1;  // +1: conflict-free strided LDS reads
 	__shared__ double tile[64 * LD];
 	const int t = threadIdx.x;
+	const long total = rows ? nlist : pat.nbrows;  // optional row list (level-scheduled factorisation)
 	const long row0 = (long)blockIdx.x * 64;
-	const long myrow = row0 + t;
-	const bool rowok = myrow < pat.nbrows;
+	const bool rowok = row0 + t < total;
+	const long myrow = rowok ? (rows ? rows[row0 + t] : row0 + t) : 0;
 	const long dgpos = rowok ? pat.diagind[myrow] : 0;
 	const long sblk = src_by_diag ? dgpos : myrow, dblk = dst_by_diag ? dgpos : myrow;
-	const int nrows = (pat.nbrows - row0) < 64 ? (int)(pat.nbrows - row0) : 64;
+	const int nrows = (total - row0) < 64 ? (int)(total - row0) : 64;
 
 	// HBM -> LDS, one block per wave instruction
 	for (int i = 0; i < nrows; i++) {
@@ -525,6 +527,9 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_factor_levels: no level schedule");
 	if (a.in != a.out)
 		BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_factor_levels: in place only");
+	// (Tried for bs = 5 / 7: the tuned pair-layout kernel per level plus a launch that inverts the level's
+	// diagonal blocks.  Two launches per level cost more than the on-the-fly inverses save: 72.8 ms
+	// instead of 52.7 ms on the unstructured bs=5 case, 21.8 against 22.1 ms at bs=7.)
 	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels are inverted on the fly
 	for (int l = 0; l < ls.nlevels; l++) {
 		a.rows = ls.rows + ls.ptr[l];
@@ -568,7 +573,7 @@ void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_b
 		if (BS >= 5) {
 			const unsigned grid = (unsigned)(((long)pat.nbrows + 63) / 64);
 			hipLaunchKernelGGL((invert_blocks_tpb_kernel<(BS >= 5 ? BS : 5), RM>), dim3(grid), dim3(64), 0, s,
-			                   pat, src, (int)src_by_diag, dst, (int)dst_by_diag);
+			                   pat, src, (int)src_by_diag, dst, (int)dst_by_diag, (const int *)nullptr, 0);
 		} else {
 			const unsigned grid = (unsigned)(((long)pat.nbrows + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
 			hipLaunchKernelGGL((invert_blocks_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, pat, src,

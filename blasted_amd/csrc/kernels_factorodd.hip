@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void factorodd_kernel(const FactorArgs a, cons
 
 	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
 	const long rowlin = (long)chunk * RPB + wave * RPW + g;
-	const bool rowok = rowlin < a.pat.nbrows;
-	const int irow = rowok ? (int)rowlin : 0;
+	const bool rowok = rowlin < (a.rows ? a.nrows : a.pat.nbrows);
+	const int irow = rowok ? (a.rows ? a.rows[rowlin] : (int)rowlin) : 0;
 	int jbeg = 0, jend = 0;
 	if (rowok) {
 		jbeg = a.pat.browptr[irow];
@@ -118,6 +118,8 @@ int g_factorodd_enabled = -1;
 
 }  // namespace
 
+static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipStream_t s);
+
 void set_factorodd_enabled(int on)
 {
 	g_factorodd_enabled = on;
@@ -136,15 +138,24 @@ bool launch_factorodd(const FactorArgs &a, double *dinv_scratch, hipStream_t s)
 	    a.rows)
 		return false;
 	launch_invert_diag_blocks(a.pat, a.in, 1, dinv_scratch, 0, s);
-	if (bs == 5) {
-		const unsigned grid = (unsigned)(((long)a.pat.nbrows + 15) / 16);
-		hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
-	} else {
-		const unsigned grid = (unsigned)(((long)a.pat.nbrows + 7) / 8);
-		hipLaunchKernelGGL(factorodd_kernel<7>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
-	}
+	launch_factorodd_rows(a, dinv_scratch, s);
 	BHIP_CHECK(hipGetLastError());
 	return true;
+}
+
+// the kernel alone over all rows or over a.rows; dinv must hold the inverses the listed rows need
+static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipStream_t s)
+{
+	const long n = a.rows ? a.nrows : a.pat.nbrows;
+	if (n <= 0)
+		return;
+	if (a.pat.bs == 5) {
+		const unsigned grid = (unsigned)((n + 15) / 16);
+		hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, dinv);
+	} else {
+		const unsigned grid = (unsigned)((n + 7) / 8);
+		hipLaunchKernelGGL(factorodd_kernel<7>, dim3(grid), dim3(256), 0, s, a, dinv);
+	}
 }
 
 }  // namespace bhip
