@@ -413,6 +413,31 @@ def test_medium_poisson_64_against_oracle():
     p.close()
 
 
+def test_config0_scalar_poisson_64_chebyshev():
+    """BASELINE config 0: tests/poisson3d-fd 64^3 scalar CSR on the reference's default Chebyshev grid
+    (input/poisson.control), async ILU(0) with 3 build and 3 apply sweeps."""
+    m = W.poisson3d(66, 1, grid="chebyshev")
+    assert m["nbrows"] == 64 ** 3
+    r = W.rhs_vector(m["nbrows"])
+    p = make_prec(m)
+    p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)
+    gf = p.get_iluvals()
+    assert rel(gf, O.ilu0_factorize(m, None, 3, mode=O.JACOBI_SYNC)["iluvals"]) < TOL_SYNC
+    z = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+    assert rel(z, O.ilu0_apply(m, gf, r, 3, mode=O.JACOBI_SYNC)) < TOL_SYNC
+    # the asynchronous forms: finite, and with enough sweeps equal to the serial (exact) result
+    p.ilu0_factorize(3, mode=capi.ASYNC)
+    assert np.isfinite(p.get_iluvals()).all()
+    nlev = 3 * 64 - 2
+    p.ilu0_factorize(nlev + 2, mode=capi.ASYNC)
+    fe = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(p.get_iluvals(), fe) < TOL_EXACT
+    ze = O.ilu0_apply(m, fe, r, 1, mode=O.GS_SERIAL)
+    assert rel(p.ilu0_apply(r, nlev + 2, mode=capi.ASYNC), ze) < TOL_EXACT
+    assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), ze) < TOL_EXACT
+    p.close()
+
+
 # ---------------------------------------------------------------------------- chaotic relaxation (gs)
 
 @pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4"])
