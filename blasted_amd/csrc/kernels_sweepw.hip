@@ -7,8 +7,8 @@
 //    range of the whole chunk are read from HBM once, coalesced, into LDS, so no value load waits on
 //    an index load from memory (the dependent chain per row is LDS -> {block, x segment} -> result);
 //  * a block is read as 16 bytes per lane (global_load_dwordx4) by LPB = bs*bs/2 lanes: lane q holds
-//    entries (2q, 2q+1) = rows 2h, 2h+1 of column c, with h = q % (bs/2), c = q / (bs/2); NB = 2 block
-//    slots per row are in flight per load instruction (bs=4: 4 rows per wave, bs=8: one);
+//    entries (2q, 2q+1) = rows 2h, 2h+1 of column c, with h = q % (bs/2), c = q / (bs/2); bs=4: one
+//    block slot per row, 8 rows per wave; bs=8: two slots, one row per wave;
 //  * all loads of a row step -- KFIX predicated block passes, straight-line, times UNR steps -- are
 //    issued before the first use; rows with more blocks finish in a remainder loop;
 //  * the x segment of a block is gathered as one double per lane (its column's entry); the mat-vec is
@@ -38,24 +38,24 @@ __device__ __forceinline__ double2_t load_block16(const double *p)
 	return *reinterpret_cast<const double2_t *>(p);
 }
 
-template <int BS>
+template <int BS, int NBV>
 struct WGeo {
 	static constexpr int HB = BS / 2;         // lanes per block column
 	static constexpr int LPB = BS * HB;       // lanes per block (16 bytes each)
-	static constexpr int NB = 2;              // block slots per row
-	static constexpr int G = LPB * NB;        // lanes per block-row: 16 (bs=4), 64 (bs=8)
+	static constexpr int NB = NBV;            // block slots per row (2, or 1 for the triangular sweeps at bs=4)
+	static constexpr int G = LPB * NB;        // lanes per block-row: 16 or 8 (bs=4), 64 (bs=8)
 	static constexpr int RPW = 64 / G;        // rows per wave and step
 	static constexpr int RSTEP = 4 * RPW;     // rows per workgroup and step
 	static constexpr int HBITS = HB == 2 ? 1 : 2;
-	static constexpr int GBITS = G == 16 ? 4 : 6;
+	static constexpr int GBITS = G == 8 ? 3 : (G == 16 ? 4 : 6);
 	static constexpr int BLKBYTES = BS * BS * 8;
 	static constexpr int ROWBYTES = BS * 8;
 };
 
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR>
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
-	using Ge = WGeo<BS>;
+	using Ge = WGeo<BS, NBV>;
 	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
 	constexpr int CAP = 8 * RCHUNK;  // staged column indices
 	static_assert(BS == 4 || BS == 8, "wide kernel: bs 4 or 8");
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 
 	// straight-line passes: 2*NB items cover a 7-point row's lower or diagonal+upper part; operators
 	// that visit the whole row (SpMV, relaxation) get twice as many
-	constexpr int KFIX = 2 * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
+	constexpr int KFIX = (4 / NB) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
 
 	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
 		int lrow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 
 struct Variant {
 	int rchunk = 128, nt = 1, unr = 2, enabled = 1;
+	int nb1 = 1;  // bs=4: one block slot per row (8 lanes per row, 8 rows per wave); 0 = two slots, 3 = triangular sweeps only
 };
 
 static Variant parse_variant(const char *e)
@@ -286,11 +287,14 @@ static Variant parse_variant(const char *e)
 		v.enabled = 0;
 		return v;
 	}
-	int r = 128, nt = 1, unr = 2;
-	if (std::sscanf(e, "r%d,nt%d,u%d", &r, &nt, &unr) == 3) {
+	int r = 128, nt = 1, unr = 2, nb1 = 1;
+	const int got = std::sscanf(e, "r%d,nt%d,u%d,s%d", &r, &nt, &unr, &nb1);
+	if (got >= 3) {
 		v.rchunk = r;
 		v.nt = nt;
 		v.unr = unr;
+		if (got == 4)
+			v.nb1 = nb1 == 1 ? 1 : (nb1 == 3 ? 3 : 0);  // ",s1" (default): one block slot per row; ",s2": two; ",s3": one for the triangular sweeps only
 	}
 	return v;
 }
@@ -316,8 +320,15 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		   keep them at one step per pass of the loop so that 8 waves per SIMD stay resident */          \
 		constexpr int UEFF = (PART == PART_ALL || PART == PART_OFFDIAG || BS == 8) ? 1 : UV;            \
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + RV - 1) / RV);                          \
-		hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UEFF>), dim3(grid),    \
-		                   dim3(256), 0, s, a);                                                        \
+		/* bs=4: one slot per row (8 lanes per row, 8 rows per wave, one step in flight) fills every load  \
+		   pass whatever the row length (a 7-point row has 3 lower blocks: with two slots its second pass \
+		   is half empty) -- ILU pair -6 %, SGS pair -11 %, SpMV -4 %, relaxation pass -5 % at 256^3 */    \
+		if (BS == 4 && v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))               \
+			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1>), dim3(grid), \
+			                   dim3(256), 0, s, a);                                                    \
+		else                                                                                           \
+			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UEFF, 2>), dim3(grid), \
+			                   dim3(256), 0, s, a);                                                    \
 		return true;                                                                                   \
 	}
 	BHIP_V(128, 1, 2)

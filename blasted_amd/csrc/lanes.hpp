@@ -43,18 +43,34 @@ __device__ __forceinline__ double xor32_sum(const double v)
 	return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
 }
 
+// v[lane ^ 4] inside every aligned group of 8 lanes: two row shifts and a select
+__device__ __forceinline__ double xor4_value(const double v, const int lane)
+{
+	const double up = dpp_mov<0x104>(v);  // row_shl:4  lane i <- lane i+4
+	const double dn = dpp_mov<0x114>(v);  // row_shr:4  lane i <- lane i-4
+	return (lane & 4) ? dn : up;
+}
+
 // All-reduce (sum) over lane bits [LOBIT, HIBIT), every other bit kept; all on the VALU.
 //  * bits 0 and 1: exact xor exchanges inside a quad (quad_perm);
 //  * bits 2 and 3 (and bit 1 when the range reaches bit 3): row rotations.  Inside a 16-lane DPP row,
 //    row_ror 8, 4, 2 applied in this order sum bits 3, 2, 1: after each step the value is periodic in the
 //    bit just summed, so the wrap-around of the next rotation lands on an equal value.  This needs the
 //    range to include bit 3 whenever it includes bit 2 (static_assert below);
-//  * bits 4 and 5: v_permlane16_swap / v_permlane32_swap.
+//  * bits 4 and 5: v_permlane16_swap / v_permlane32_swap;
+//  * the range [1, 3) (8-lane groups) is done with exact xor exchanges: quad_perm and xor4_value.
 template <int LOBIT, int HIBIT>
 __device__ __forceinline__ double allreduce_bits(double v)
 {
 	static_assert(HIBIT <= 6 && LOBIT >= 0 && LOBIT <= HIBIT, "lane bits");
-	static_assert(!(LOBIT <= 2 && HIBIT > 2) || HIBIT > 3, "a range containing bit 2 must contain bit 3");
+	if (LOBIT == 1 && HIBIT == 3) {
+		// bits 1 and 2 only (8-lane groups): exact xor exchanges, no rotation (bit 3 is not summed)
+		v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+		v += xor4_value(v, (int)(threadIdx.x & 63));
+		return v;
+	}
+	static_assert(!(LOBIT <= 2 && HIBIT > 2) || HIBIT > 3 || (LOBIT == 1 && HIBIT == 3),
+	              "a range containing bit 2 must contain bit 3 (except the 8-lane case handled above)");
 	constexpr bool rot = HIBIT > 3;  // rotations usable for bits 1..3
 	if (LOBIT <= 3 && HIBIT > 3)
 		v += dpp_mov<0x128>(v);  // row_ror:8

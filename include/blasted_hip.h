@@ -168,7 +168,8 @@ int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long
 int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
 
 /* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
- * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>" for the tuned bs=4/8 kernel; the same strings
+ * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>[,s<1|2|3>]" for the tuned bs=4/8 kernel (s: block
+ * slots per row at bs=4 -- 1 (default), 2, or 3 = one slot for the triangular sweeps only); the same strings
  * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
  * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
  * "factorodd=0" / "factorodd=1": tuned bs=5/7 factorisation kernel off / on (BLASTED_HIP_FACTORODD).
