@@ -7,8 +7,8 @@
 //    range of the whole chunk are read from HBM once, coalesced, into LDS, so no value load waits on
 //    an index load from memory (the dependent chain per row is LDS -> {block, x segment} -> result);
 //  * a block is read as 16 bytes per lane (global_load_dwordx4) by LPB = bs*bs/2 lanes: lane q holds
-//    entries (2q, 2q+1) = rows 2h, 2h+1 of column c, with h = q % (bs/2), c = q / (bs/2); bs=4: one
-//    block slot per row, 8 rows per wave; bs=8: two slots, one row per wave;
+//    entries (2q, 2q+1) = rows 2h, 2h+1 of column c, with h = q % (bs/2), c = q / (bs/2); one block
+//    slot per row: 8 rows per wave at bs=4, 2 at bs=8;
 //  * all loads of a row step -- KFIX predicated block passes, straight-line, times UNR steps -- are
 //    issued before the first use; rows with more blocks finish in a remainder loop;
 //  * the x segment of a block is gathered as one double per lane (its column's entry); the mat-vec is
@@ -47,7 +47,7 @@ struct WGeo {
 	static constexpr int RPW = 64 / G;        // rows per wave and step
 	static constexpr int RSTEP = 4 * RPW;     // rows per workgroup and step
 	static constexpr int HBITS = HB == 2 ? 1 : 2;
-	static constexpr int GBITS = G == 8 ? 3 : (G == 16 ? 4 : 6);
+	static constexpr int GBITS = G == 8 ? 3 : (G == 16 ? 4 : (G == 32 ? 5 : 6));
 	static constexpr int BLKBYTES = BS * BS * 8;
 	static constexpr int ROWBYTES = BS * 8;
 };
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 
 struct Variant {
 	int rchunk = 128, nt = 1, unr = 2, enabled = 1;
-	int nb1 = 1;  // bs=4: one block slot per row (8 lanes per row, 8 rows per wave); 0 = two slots, 3 = triangular sweeps only
+	int nb1 = 1;  // one block slot per row (bs=4: 8 lanes per row, 8 rows per wave; bs=8: 32 lanes, 2 rows); 0 = two slots, 3 = triangular sweeps only
 };
 
 static Variant parse_variant(const char *e)
@@ -320,10 +320,11 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		   keep them at one step per pass of the loop so that 8 waves per SIMD stay resident */          \
 		constexpr int UEFF = (PART == PART_ALL || PART == PART_OFFDIAG || BS == 8) ? 1 : UV;            \
 		const unsigned grid = (unsigned)(((long)a.pat.nbrows + RV - 1) / RV);                          \
-		/* bs=4: one slot per row (8 lanes per row, 8 rows per wave, one step in flight) fills every load  \
-		   pass whatever the row length (a 7-point row has 3 lower blocks: with two slots its second pass \
-		   is half empty) -- ILU pair -6 %, SGS pair -11 %, SpMV -4 %, relaxation pass -5 % at 256^3 */    \
-		if (BS == 4 && v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))               \
+		/* one slot per row (bs=4: 8 lanes per row, 8 rows per wave; bs=8: 32 lanes, 2 rows; one step in   \
+		   flight) fills every load pass whatever the row length (a 7-point row has 3 lower blocks: with  \
+		   two slots its second pass is half empty) -- bs=4 at 256^3: ILU pair -6 %, SGS pair -11 %, SpMV \
+		   -4 %, relaxation pass -5 %; bs=8 at 100^3: lower sweep 4.6 -> 6.3 TB/s, SpMV 5.1 -> 5.9 */      \
+		if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                         \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1>), dim3(grid), \
 			                   dim3(256), 0, s, a);                                                    \
 		else                                                                                           \
