@@ -177,3 +177,22 @@ def test_level_mode_rejected_by_factorize(golden):
     with pytest.raises(capi.BlastedHipError):
         p.ilu0_factorize(1, mode=capi.LEVEL)
     p.close()
+
+
+def test_exact_pass_is_bit_reproducible(level_impl):
+    """An exact pass is deterministic -- each row is one fixed expression of final inputs -- whatever the
+    order in which waves happen to run: repeated applies agree bit for bit, and none gives up waiting
+    (tools/soak_exact.py is the long version of this test)."""
+    m = W.poisson3d(34, 4, grid="uniform")
+    n = m["nbrows"] * 4
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.ilu0_factorize(2)
+    p.jacobi_compute()
+    z0 = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+    s0 = p.sgs_apply(r, 1, mode=capi.LEVEL)
+    for _ in range(40):
+        assert np.array_equal(p.ilu0_apply(r, 1, mode=capi.LEVEL), z0)
+        assert np.array_equal(p.sgs_apply(r, 1, mode=capi.LEVEL), s0)
+    check_stats(p, level_impl)
+    p.close()
