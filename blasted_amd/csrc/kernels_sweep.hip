@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 				const int jj = jbeg[q] + slot + k * NB;
 				bv[q][k] = 0.0;
 				xv[q][k] = 0.0;
-				if (PART != PART_NONE && jj < jend[q] && active) {
+				// (relaxation: the diagonal block of A is not part of the sum -- do not fetch it)
+				if (PART != PART_NONE && jj < jend[q] && active && !(PART == PART_OFFDIAG && jj == dg[q])) {
 					bv[q][k] = *reinterpret_cast<const double *>(
 					    vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
 					const bool isdiag = (jj == dg[q]);

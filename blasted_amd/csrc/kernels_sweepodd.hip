@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 			const int jj = jbeg + k;
 			bv[k].x = bv[k].y = 0.0;
 			xv[k].x = xv[k].y = 0.0;
-			if (PART != PART_NONE && jj < jend && actB) {
+			// (relaxation: the diagonal block of A is not part of the sum -- do not fetch it)
+			if (PART != PART_NONE && jj < jend && actB && !(PART == PART_OFFDIAG && jj == dg)) {
 				bv[k] = load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
 				const bool isdiag = (jj == dg);
 				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				bv[u][k].x = 0.0;
 				bv[u][k].y = 0.0;
 				xv[u][k] = 0.0;
-				if (PART != PART_NONE && jj < jend[u]) {
+				// (relaxation: the diagonal block of A is not part of the sum -- do not fetch it)
+				if (PART != PART_NONE && jj < jend[u] && !(PART == PART_OFFDIAG && jj == dgp[u])) {
 					bv[u][k] = load_block16<NT>(reinterpret_cast<const double *>(
 					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
 					const bool isdiag = (jj == dgp[u]);
