@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Cost of the copy pass that refreshes the compact / level-ordered copies of the factor after a
+factorisation (first apply after factorize minus a steady-state apply), 256^3 bs=4."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from blasted_amd import capi, workloads as W
 dev = torch.device("cuda", 0)
 m = W.poisson3d_device(256, 4, dev, grid="uniform")
