@@ -195,60 +195,61 @@ static int g_compact = [] {
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 }();
 
-// Points the sweep arguments at the compact copy of one triangle of the factor (refreshed after a
-// factorisation).  In the copy a row's part is its whole row: browptr/diagind are set so that the
-// LOWER / UPPER kernels see exactly that.
-static void compact_factor_args(blasted_hip_prec p, bool upper, SweepArgs &a)
+// Brings the two-triangle copy `c` of the block array `src` up to date in the storage `st`.
+static void refresh_copy(blasted_hip_prec p, const LevelSchedule &st, const double *src,
+                         blasted_hip_prec_s::TriCopy &c)
+{
+	const long bs2 = (long)p->pat.bs * p->pat.bs;
+	if (!c.l) {
+		c.l = dev_alloc<double>((size_t)(st.nnz_lower * bs2));
+		c.u = dev_alloc<double>((size_t)(st.nnz_dupper * bs2));
+		c.valid = false;
+	}
+	if (!c.valid) {
+		launch_level_permute_values(p->pat, st, src, c.l, c.u, p->stream);
+		c.valid = true;
+	}
+}
+
+// Points the sweep arguments at the natural-order compact copy of one triangle of `src` (the factor or
+// the matrix).  In the copy a row's part is its whole row: browptr/diagind are set so that the LOWER /
+// UPPER kernels see exactly that.
+static void compact_args(blasted_hip_prec p, bool upper, SweepArgs &a, const double *src,
+                         blasted_hip_prec_s::TriCopy &c)
 {
 	LevelSchedule &ns = p->natstore;
 	build_natural_storage(p->pat, ns, p->stream);
-	const long bs2 = (long)p->pat.bs * p->pat.bs;
-	if (!p->nlfac) {
-		p->nlfac = dev_alloc<double>((size_t)(ns.nnz_lower * bs2));
-		p->nufac = dev_alloc<double>((size_t)(ns.nnz_dupper * bs2));
-		p->nfac_valid = false;
-	}
-	if (!p->nfac_valid) {
-		launch_level_permute_values(p->pat, ns, p->iluvals, p->nlfac, p->nufac, p->stream);
-		p->nfac_valid = true;
-	}
+	refresh_copy(p, ns, src, c);
 	if (upper) {
 		a.pat.browptr = ns.uptr;
 		a.pat.diagind = ns.uptr;  // the diagonal block is the first of a row of this copy
 		a.pat.bcolind = ns.ucol;
-		a.vals = p->nufac;
-		a.dvals = p->nufac;
+		a.vals = c.u;
+		if (a.dvals == src)
+			a.dvals = c.u;
 	} else {
 		a.pat.browptr = ns.lptr;
 		a.pat.diagind = ns.lptr + 1;  // the lower part ends where the next row starts
 		a.pat.bcolind = ns.lcol;
-		a.vals = p->nlfac;
+		a.vals = c.l;
 	}
 }
 
-// The level-ordered view of the factor's lower or diagonal+upper triangle, refreshed after a
-// factorisation; false when the copies are switched off.
-static bool factor_view(blasted_hip_prec p, bool upper, LevelView &v)
+// The level-ordered view of the lower or diagonal+upper triangle of `src`; false when the copies are
+// switched off.
+static bool level_view(blasted_hip_prec p, bool upper, LevelView &v, const double *src,
+                       blasted_hip_prec_s::TriCopy &c)
 {
 	if (!g_level_store)
 		return false;
 	LevelSchedule &ls = need_levels(p);
 	build_level_storage(p->pat, ls, p->stream);
-	const long bs2 = (long)p->pat.bs * p->pat.bs;
-	if (!p->lfac) {
-		p->lfac = dev_alloc<double>((size_t)(ls.nnz_lower * bs2));
-		p->ufac = dev_alloc<double>((size_t)(ls.nnz_dupper * bs2));
-		p->lfac_valid = false;
-	}
-	if (!p->lfac_valid) {
-		launch_level_permute_values(p->pat, ls, p->iluvals, p->lfac, p->ufac, p->stream);
-		p->lfac_valid = true;
-	}
+	refresh_copy(p, ls, src, c);
 	v.meta = upper ? ls.umeta : ls.lmeta;
 	v.ptr = upper ? ls.uptr : ls.lptr;
 	v.head = upper ? ls.uhead : ls.lhead;
 	v.bcolind = upper ? ls.ucol : ls.lcol;
-	v.vals = upper ? p->ufac : p->lfac;
+	v.vals = upper ? c.u : c.l;
 	return true;
 }
 
@@ -261,7 +262,11 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 	if (g_level_impl == 0) {
 		LevelView view;
 		const bool triangular = part == PART_LOWER || part == PART_UPPER;
-		const bool use_view = triangular && a.vals == p->iluvals && factor_view(p, part == PART_UPPER, view);
+		bool use_view = false;
+		if (triangular && a.vals == p->iluvals)
+			use_view = level_view(p, part == PART_UPPER, view, p->iluvals, p->fac_lvl);
+		else if (triangular && a.vals == p->vals)
+			use_view = level_view(p, part == PART_UPPER, view, p->vals, p->mat_lvl);
 		launch_syncfree_fill(x, p->n(), p->stream);
 		a.xin = xold ? xold : x;
 		a.xout = x;
@@ -408,11 +413,11 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		}
 		dev_free(p->red);
 		free_level_schedule(p->levels);
-		dev_free(p->lfac);
-		dev_free(p->ufac);
 		free_level_schedule(p->natstore);
-		dev_free(p->nlfac);
-		dev_free(p->nufac);
+		for (auto *c : {&p->fac_nat, &p->fac_lvl, &p->mat_nat, &p->mat_lvl}) {
+			dev_free(c->l);
+			dev_free(c->u);
+		}
 		if (p->own_stream)
 			(void)hipStreamDestroy(p->stream);
 		delete p;
@@ -510,6 +515,8 @@ int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
 			BHIP_CHECK(hipStreamSynchronize(p->stream));
 			p->vals = p->vals_own;
 		}
+		p->mat_nat.valid = false;
+		p->mat_lvl.valid = false;
 	});
 }
 
@@ -564,8 +571,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
-		p->lfac_valid = false;
-		p->nfac_valid = false;
+		p->fac_lvl.valid = false;
+		p->fac_nat.valid = false;
 		if (mode == BLASTED_HIP_LEVEL)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
 			                              "points; the exact factorisation is nbuildsweeps < 0");
@@ -715,7 +722,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0;
 		if (compact)
-			compact_factor_args(p, false, a);
+			compact_args(p, false, a, p->iluvals, p->fac_nat);
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, nullptr,
 		                       napplysweeps, mode, 0);
@@ -728,7 +735,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rhs = y;
 		a.descending = 1;
 		if (compact)
-			compact_factor_args(p, true, a);
+			compact_args(p, true, a, p->iluvals, p->fac_nat);
 		const DSrc dsrc = scalar ? D_RECIP_DIAG : D_VALS_DIAG;
 		double *zfinal = dz;
 		if (napplysweeps == 0) {
@@ -789,6 +796,8 @@ int blasted_hip_jacobi_compute(blasted_hip_prec p)
 		ph.launches = 1;
 		ph.done();
 		p->jacobi_done = true;
+		p->mat_nat.valid = false;  // compute(): the borrowed values may have changed in place
+		p->mat_lvl.valid = false;
 		if (!p->ytemp) {  // AsyncBlockSGS::compute, src/solverops_sgs.cpp:33-45
 			p->ytemp = dev_alloc<double>((size_t)p->n());
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, sizeof(double) * (size_t)p->n(), p->stream));
@@ -861,6 +870,9 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		a.dvals = p->dblocks;
 		a.rhs = dr;
 		a.descending = 0;
+		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0;
+		if (compact)
+			compact_args(p, false, a, p->vals, p->mat_nat);
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y = run_sweeps(p, a, PART_LOWER, POST_D_SUB, D_DBLOCKS, p->ytemp, yother, nullptr,
 		                       napplysweeps, mode, 0);
@@ -874,6 +886,8 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		a.dvals = p->dblocks;
 		a.rhs = y;
 		a.descending = 1;
+		if (compact)
+			compact_args(p, true, a, p->vals, p->mat_nat);
 		const double *first_in = nullptr;
 		if (apply_init == BLASTED_HIP_INIT_A_JACOBI) {
 			if (napplysweeps == 0)

@@ -212,11 +212,14 @@ struct blasted_hip_prec_s {
 	double *red = nullptr;                           // small reduction scratch
 
 	bhip::LevelSchedule levels;
-	double *lfac = nullptr, *ufac = nullptr;  // level-ordered copies of the factor's triangles
-	bool lfac_valid = false;
-	bhip::LevelSchedule natstore;               // natural-order compact triangle storage (pattern part)
-	double *nlfac = nullptr, *nufac = nullptr;  // ... and the factor's values in it
-	bool nfac_valid = false;
+	// second copies of the factor and of the matrix, split into the strictly-lower and the diagonal+upper
+	// triangle: natural row order (asynchronous sweeps) and level order (exact passes)
+	struct TriCopy {
+		double *l = nullptr, *u = nullptr;
+		bool valid = false;
+	};
+	bhip::LevelSchedule natstore;  // natural-order compact triangle storage (pattern part)
+	TriCopy fac_nat, fac_lvl, mat_nat, mat_lvl;
 
 	bhip::Timing timing;
 

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void sf_sweep_kernel(const SweepArgs a, const 
 				if (DIAG_RIDES && jj == dg) {
 					d[st] = (DSRC == D_VALS_DIAG) ? v : 1.0 / v;
 				} else {
-					const int idx = slot + k * NB;  // item number inside the row part (copies: jbeg is its start)
+					const int idx = jj - (PART == PART_LOWER ? rp0 : dg);  // item number inside the copy's row
 					int col;
 					if (head && idx < 4)
 						col = idx == 0 ? hd[st].x : (idx == 1 ? hd[st].y : (idx == 2 ? hd[st].z : hd[st].w));
