@@ -73,6 +73,64 @@ def read_mtx_bsr(path, bs, rowmajor=False):
     return coo_to_bsr(nr, rows, cols, vals, bs, rowmajor)
 
 
+# ----------------------------------------------------------------------------- PETSc binary files
+# What the reference's PETSc drivers load (MatLoad / VecLoad in tests/testutils.cpp and the
+# tests/input/**/*.pmat fixtures): big-endian; Mat = {1211216, rows, cols, nnz, rowlengths[rows],
+# colidx[nnz], values[nnz]}, Vec = {1211214, n, values[n]}.
+
+PETSC_MAT_CLASSID, PETSC_VEC_CLASSID = 1211216, 1211214
+
+
+def read_petsc_mat_coo(path):
+    """PETSc binary AIJ matrix -> (nrows, ncols, rows, cols, vals), 0-based."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    head = raw[:16].view(">i4")
+    if int(head[0]) != PETSC_MAT_CLASSID:
+        raise ValueError("not a PETSc binary matrix: " + path)
+    nr, nc, nnz = int(head[1]), int(head[2]), int(head[3])
+    if nnz < 0:
+        raise ValueError("dense PETSc binary matrices are not supported: " + path)
+    o = 16
+    lens = raw[o:o + 4 * nr].view(">i4").astype(np.int64)
+    o += 4 * nr
+    cols = raw[o:o + 4 * nnz].view(">i4").astype(np.int64)
+    o += 4 * nnz
+    vals = raw[o:o + 8 * nnz].view(">f8").astype(np.float64)
+    if int(lens.sum()) != nnz or o + 8 * nnz != raw.size:
+        raise ValueError("inconsistent PETSc binary matrix: " + path)
+    rows = np.repeat(np.arange(nr, dtype=np.int64), lens)
+    return nr, nc, rows, cols, vals
+
+
+def read_petsc_vec(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    head = raw[:8].view(">i4")
+    if int(head[0]) != PETSC_VEC_CLASSID:
+        raise ValueError("not a PETSc binary vector: " + path)
+    n = int(head[1])
+    if raw.size != 8 + 8 * n:
+        raise ValueError("inconsistent PETSc binary vector: " + path)
+    return raw[8:].view(">f8").astype(np.float64)
+
+
+def read_petsc_bsr(path, bs=None, rowmajor=False):
+    """PETSc binary matrix -> BSR dict.  bs = None reads the block size from the `.info` file next to it
+    (`-matload_block_size N`, what MatLoad honours), 1 if there is none."""
+    if bs is None:
+        bs = 1
+        try:
+            for tok in open(path + ".info").read().split("\n"):
+                t = tok.split()
+                if len(t) == 2 and t[0] == "-matload_block_size":
+                    bs = int(t[1])
+        except OSError:
+            pass
+    nr, nc, rows, cols, vals = read_petsc_mat_coo(path)
+    if nr != nc:
+        raise ValueError("square matrix required")
+    return coo_to_bsr(nr, rows, cols, vals, bs, rowmajor)
+
+
 def convert_layout(m, rowmajor):
     """Same matrix with the other in-block layout."""
     if bool(m["rowmajor"]) == bool(rowmajor):

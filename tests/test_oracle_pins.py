@@ -405,3 +405,24 @@ def test_level_schedule_and_level_operators_equal_serial(gen):
     z0 = O.ilu0_apply(m, f0, r[np.argsort(perm)], 1, mode=O.GS_SERIAL)
     zp = O.ilu0_apply(mp, f, r, 1, mode=O.GS_SERIAL)
     assert np.abs(zp - z0[perm]).max() <= 1e-12 * np.abs(z0).max()
+
+
+# ---------------------------------------------------------------------------- PETSc binary fixtures
+
+def test_petsc_binary_fixture_equals_matrix_market(golden):
+    """tests/input/fvens-2dcyl1/2dcyl1{,_b,_x}.pmat -- what the reference's PETSc drivers MatLoad/VecLoad
+    (block size 4 from the .info file) -- hold the same system as the Matrix-Market copies."""
+    from blasted_amd import mtxio
+    mp = mtxio.read_petsc_bsr(os.path.join(golden, "2dcyl1.pmat"))
+    mm = mtxio.read_mtx_bsr(os.path.join(golden, "2dcyl1.mtx"), 4)
+    assert mp["bs"] == 4 and mp["nbrows"] == 446
+    for k in ("browptr", "bcolind", "diagind"):
+        assert np.array_equal(mp[k], mm[k])                      # integer structure: bit-exact
+    assert np.abs(mp["vals"] - mm["vals"]).max() <= 1e-15 * np.abs(mm["vals"]).max()   # 17-digit text
+    b = mtxio.read_petsc_vec(os.path.join(golden, "2dcyl1_b.pmat"))
+    x = mtxio.read_petsc_vec(os.path.join(golden, "2dcyl1_x.pmat"))
+    assert np.abs(b - mtxio.read_mtx_dense(os.path.join(golden, "2dcyl1_b.mtx"))).max() <= 1e-15 * np.abs(b).max()
+    assert np.abs(x - mtxio.read_mtx_dense(os.path.join(golden, "2dcyl1_x.mtx"))).max() <= 1e-15 * np.abs(x).max()
+    # and the shipped solution solves the shipped system with the oracle's SpMV
+    r = b - O.spmv(mp, x)
+    assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-6
