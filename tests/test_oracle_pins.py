@@ -426,3 +426,26 @@ def test_petsc_binary_fixture_equals_matrix_market(golden):
     # and the shipped solution solves the shipped system with the oracle's SpMV
     r = b - O.spmv(mp, x)
     assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-6
+
+
+def test_coo_to_bsr_matches_reference_block_coo_fixture(golden):
+    """tests/mat_ops/input/small_block3_matrix_sorted_bcolmajor.bcoo is the reference's expected
+    column-major BSR form of small_block3_matrix.mtx with sorted block columns
+    (tests/mat_ops/CMakeLists.txt:47-51): header, browptr, 1-based block rows / columns, block values,
+    diagonal positions."""
+    from blasted_amd import mtxio
+    tok = open(os.path.join(golden, "small_block3_matrix_sorted_bcolmajor.bcoo")).read().split()
+    nbr, nbc, nnzb = (int(t) for t in tok[:3])
+    browptr = np.array(tok[3:3 + nbr + 1], dtype=np.int32)
+    brow = np.array(tok[4 + nbr:4 + nbr + nnzb], dtype=np.int32) - 1
+    bcol = np.array(tok[4 + nbr + nnzb:4 + nbr + 2 * nnzb], dtype=np.int32) - 1
+    v0 = 4 + nbr + 2 * nnzb
+    vals = np.array(tok[v0:v0 + 9 * nnzb], dtype=np.float64)
+    diagind = np.array(tok[v0 + 9 * nnzb:], dtype=np.int32)     # last line: storage position of each diagonal block
+    m = mtxio.read_mtx_bsr(os.path.join(golden, "small_block3_matrix.mtx"), 3, rowmajor=False)
+    assert (m["nbrows"], m["nnzb"]) == (nbr, nnzb) and nbr == nbc
+    assert np.array_equal(m["browptr"], browptr)
+    assert np.array_equal(m["bcolind"], bcol)
+    assert np.array_equal(np.repeat(np.arange(nbr), np.diff(browptr)), brow)
+    assert vals.size == nnzb * 9 and np.array_equal(m["vals"], vals)
+    assert np.array_equal(m["diagind"], diagind)
