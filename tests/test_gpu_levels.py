@@ -196,3 +196,25 @@ def test_exact_pass_is_bit_reproducible(level_impl):
         assert np.array_equal(p.sgs_apply(r, 1, mode=capi.LEVEL), s0)
     check_stats(p, level_impl)
     p.close()
+
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "msc_csr"])
+def test_no_dependence_inside_a_level(golden, case):
+    """The reference's own level-schedule test (tests/mat_ops/testlevelschedule.cpp:18-48, run on 2dcyl1
+    bs=4 and msc00726 bs=1, tests/mat_ops/CMakeLists.txt:126-132): no row of a level has a stored block
+    in the column of another row of the same level."""
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    lv, rows, ptr = p.get_levels()
+    rp, ci = m["browptr"], m["bcolind"]
+    rowof = np.repeat(np.arange(m["nbrows"]), np.diff(rp))
+    off = rowof != ci
+    assert not np.any(lv[rowof[off]] == lv[ci[off]])
+    # and the same check, literally, on the reference's consecutive-row levels of the level-ordered matrix
+    mp = W.permute_symmetric(m, rows)
+    levels = O.compute_levels(mp)
+    lvl_of = np.repeat(np.arange(levels.size - 1), np.diff(levels))
+    rowofp = np.repeat(np.arange(mp["nbrows"]), np.diff(mp["browptr"]))
+    offp = rowofp != mp["bcolind"]
+    assert not np.any(lvl_of[rowofp[offp]] == lvl_of[mp["bcolind"][offp]])
+    p.close()
