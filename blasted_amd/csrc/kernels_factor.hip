@@ -527,6 +527,10 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 		BHIP_FAIL(BLASTED_HIP_ESTATE, "launch_factor_levels: no level schedule");
 	if (a.in != a.out)
 		BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_factor_levels: in place only");
+	// (Tried: the whole factorisation as ONE dependency-polling launch like the exact solves -- rows wait
+	// for their lower neighbours' "finished" flags, factor entries read with agent-scope atomic loads.  It
+	// is correct but several times slower than one launch per level (256^3 bs=4: 167 ms against 29.5 ms):
+	// a row walks its entries sequentially through ~20 dependent, now uncached, loads.)
 	// (Tried for bs = 5 / 7: the tuned pair-layout kernel per level plus a launch that inverts the level's
 	// diagonal blocks.  Two launches per level cost more than the on-the-fly inverses save: 72.8 ms
 	// instead of 52.7 ms on the unstructured bs=5 case, 21.8 against 22.1 ms at bs=7.)
