@@ -1162,6 +1162,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_level_store = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "level=", 6) == 0)
 			g_level_impl = std::strcmp(spec + 6, "launch") == 0 ? 1 : 0;
+		else if (spec && std::strncmp(spec, "sweepwr=", 8) == 0)
+			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
 			set_sweepodd_enabled(spec[9] != '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)

@@ -124,6 +124,9 @@ void set_sweep_unroll(int u);
 // kernels_sweepw.hip (tuned bs=4/8 column-major path; false = not covered, use the generic family)
 bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepw_variant(const char *spec);
+// kernels_sweepwr.hip (tuned bs=4/8 ROW-major path; false = not covered)
+bool launch_sweepwr(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+void set_sweepwr_enabled(int on);
 // kernels_sweepodd.hip (tuned bs=3/5/7 column-major path; false = not covered)
 bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepodd_enabled(int on);

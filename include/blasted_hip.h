@@ -173,6 +173,7 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
  * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
  * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
  * "factorodd=0" / "factorodd=1": tuned bs=5/7 factorisation kernel off / on (BLASTED_HIP_FACTORODD).
+ * "sweepwr=0" / "sweepwr=1": tuned row-major bs=4/8 sweep kernel off / on (BLASTED_HIP_SWEEPWR).
  * "sweepodd=0" / "sweepodd=1": tuned bs=3/5/7 sweep kernel off / on (environment: BLASTED_HIP_SWEEPODD).
  * "level=syncfree" (default) / "level=launch": exact passes as one persistent launch or as one launch
  * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":

@@ -374,8 +374,9 @@ def test_solve_known_answer_on_gpu(golden, mat, bs, rowmajor, prec):
 
 def test_tiny_and_ragged_matrices(factor_storage):
     # 1 block-row; rows with empty lower / upper parts; row count not a multiple of the rows per workgroup
-    for nb, bs in ((1, 4), (2, 5), (3, 1), (17, 4), (65, 8), (5, 3), (129, 7), (33, 3), (131, 5), (9, 2)):
-        m = W.random_bsr(nb, bs, avg_offdiag=2, seed=nb)
+    for nb, bs, rm in ((1, 4, 0), (2, 5, 0), (3, 1, 0), (17, 4, 0), (65, 8, 0), (5, 3, 0), (129, 7, 0), (33, 3, 0),
+                       (131, 5, 0), (9, 2, 0), (150, 4, 1), (67, 8, 1), (40, 5, 1)):
+        m = W.random_bsr(nb, bs, avg_offdiag=2 if not rm else 9, seed=nb, rowmajor=bool(rm))
         n = nb * bs
         r = W.rhs_vector(n)
         p = make_prec(m)

@@ -1,0 +1,23 @@
+import sys, time, torch
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from blasted_amd import capi, workloads as W
+dev = torch.device("cuda", 0)
+for bs in (4, 8):
+    n = 160 if bs == 4 else 100
+    m = W.poisson3d_device(n, bs, dev, grid="uniform")
+    # row-major copy: transpose every block
+    v = m["vals"].view(-1, bs, bs).transpose(1, 2).contiguous().view(-1)
+    mr = dict(m); mr["vals"] = v; mr["rowmajor"] = True
+    r = W.rhs_vector_device(m["nbrows"] * bs, dev); z = torch.zeros_like(r)
+    for name, mm in (("colmajor", m), ("rowmajor", mr)):
+        p = capi.Prec(0, torch.cuda.current_stream().cuda_stream); p.set_matrix(mm); p.ilu0_factorize(2); p.jacobi_compute()
+        for spec in ("sweepwr=0", "sweepwr=1"):
+            capi.set_tuning(spec)
+            def t(fn, reps=10):
+                fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps): fn()
+                torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+            print("bs=%d %s %s: ilu apply s=3 %.3f ms, sgs apply s=3 %.3f ms, spmv %.3f ms, relax 1 it %.3f ms" % (
+                bs, name, spec, t(lambda: p.ilu0_apply(r, 3, out=z)), t(lambda: p.sgs_apply(r, 3, out=z)),
+                t(lambda: p.spmv(r, out=z)), t(lambda: p.sgs_relax(r, z, 1))), flush=True)
+        p.close()
