@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""A/B of the tuned row-major bs=4/8 sweep kernel (tuning "sweepwr=0/1") beside the column-major one on the
+same matrix with transposed blocks."""
 import sys, time, torch
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from blasted_amd import capi, workloads as W

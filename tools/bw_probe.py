@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""HBM ceilings of the box with torch ops: copy (read + write) and read-only reduction, the practical limits the
+roofline fractions in DESIGN.md are read against."""
 import torch, time
 dev=torch.device('cuda')
 n=(1<<32)//8
