@@ -27,7 +27,7 @@ SYMBOLS = [
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
     "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
-    "blasted_hip_get_levels", "blasted_hip_level_stats",
+    "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
 ]
 
 _lib = None
@@ -67,6 +67,7 @@ def lib():
         _lib.blasted_hip_ilu0_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
         _lib.blasted_hip_jacobi_compute.argtypes = [vp]
         _lib.blasted_hip_jacobi_apply.argtypes = [vp, vp, vp, ci]
+        _lib.blasted_hip_jacobi_relax.argtypes = [vp, vp, vp, ci, ci, cd, cd, cd, C.POINTER(ci), ci]
         _lib.blasted_hip_sgs_apply.argtypes = [vp, vp, vp, ci, ci, ci, ci]
         _lib.blasted_hip_sgs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
         _lib.blasted_hip_gs_relax.argtypes = [vp, vp, vp, ci, ci, ci]
@@ -214,6 +215,14 @@ class Prec:
         z = self._vec_out(r) if out is None else out
         _check(lib().blasted_hip_jacobi_apply(self._h, _ptr(r), _ptr(z), _loc(r)))
         return z
+
+    def jacobi_relax(self, b, x, maxits, check_tol=False, rtol=0.0, atol=0.0, dtol=1e300):
+        """Synchronous Jacobi relaxation steps; x is updated in place; returns the number of steps taken."""
+        b = self._prep(b)
+        n = C.c_int(0)
+        _check(lib().blasted_hip_jacobi_relax(self._h, _ptr(b), _ptr(x), int(maxits), int(bool(check_tol)),
+                                              float(rtol), float(atol), float(dtol), C.byref(n), _loc(b)))
+        return n.value
 
     def sgs_apply(self, r, napplysweeps, init=INIT_A_ZERO, mode=ASYNC, out=None):
         r = self._prep(r)

@@ -979,6 +979,67 @@ int blasted_hip_gs_relax(blasted_hip_prec p, const double *b, double *x, int nsw
 	return relax_impl(p, b, x, nsweeps, mode, loc, false);
 }
 
+// BJacobiSRPreconditioner::apply_relax, src/solverops_jacobi.cpp:66-119: synchronous (block-)Jacobi steps
+// x <- D^-1 (b - (A - D) x); with check_tol the step difference ||x_new - x_old||_2 is tested against
+// atol, and relative to the first step's against rtol (converged) and dtol (diverged).
+int blasted_hip_jacobi_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int check_tol,
+                             double rtol, double atol, double dtol, int *steps_done, int loc)
+{
+	return guarded([&] {
+		use_device(p);
+		check_loc(loc);
+		need_jacobi(p);
+		if (!b || !x || maxits < 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "jacobi_relax: null vector or negative iteration count");
+		const long n = p->n();
+		const size_t nbytes = sizeof(double) * (size_t)n;
+		const double *db = in_vec(p, b, loc, 0);
+		double *dx;
+		if (loc == BLASTED_HIP_DEVICE)
+			dx = x;
+		else {
+			dx = ensure(p->stage[1], n);
+			BHIP_CHECK(hipMemcpyAsync(dx, x, nbytes, hipMemcpyHostToDevice, p->stream));
+		}
+		double *other = ensure(p->tmp[0], n);
+		if (check_tol)
+			ensure(p->red, 1024);
+		SweepArgs a = base_args(p);
+		a.vals = p->vals;
+		a.dvals = p->dblocks;
+		a.rhs = db;
+		a.descending = 0;
+		double *cur = dx;
+		double refdiffnorm = 1.0;
+		int step = 0;
+		for (; step < maxits; step++) {
+			double *o = (cur == dx) ? other : dx;
+			Phase ph(p, 0);
+			a.xin = cur;
+			a.xout = o;
+			launch_sweep(a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, p->stream);
+			ph.launches = 1;
+			ph.done();
+			if (check_tol) {
+				const double diffnorm = run_diff_norm(o, cur, n, p->red, p->stream);
+				cur = o;
+				if (step == 0)
+					refdiffnorm = diffnorm;
+				if (diffnorm < atol || diffnorm / refdiffnorm < rtol || diffnorm / refdiffnorm > dtol) {
+					step++;
+					break;
+				}
+			} else
+				cur = o;
+		}
+		if (steps_done)
+			*steps_done = step;
+		if (cur != dx)
+			BHIP_CHECK(hipMemcpyAsync(dx, cur, nbytes, hipMemcpyDeviceToDevice, p->stream));
+		finish_out(p, x, dx, loc);
+	});
+}
+
 /* ---- level schedule -------------------------------------------------------------------------- */
 
 int blasted_hip_level_schedule(blasted_hip_prec p)

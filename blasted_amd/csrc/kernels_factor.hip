@@ -597,6 +597,43 @@ void launch_scaling_vector(const Pattern &pat, const double *vals, double *scale
 	BHIP_CHECK(hipGetLastError());
 }
 
+// partial[b] = sum over workgroup b's slice of (x[i] - y[i])^2
+__global__ __launch_bounds__(256) void diff_norm2_kernel(const double *x, const double *y, long n, double *partial)
+{
+	__shared__ double wsum[4];
+	double acc = 0.0;
+	for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+		const double d = x[i] - y[i];
+		acc += d * d;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		acc += __shfl_xor(acc, off, 64);
+	if ((threadIdx.x & 63) == 0)
+		wsum[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ||x - y||_2 (BJacobiSRPreconditioner::apply_relax's convergence check, src/solverops_jacobi.cpp:91-101);
+// dev_scratch: at least 1024 doubles; the partial sums are added on the host in fixed order
+double run_diff_norm(const double *x, const double *y, long n, double *dev_scratch, hipStream_t s)
+{
+	if (n == 0)
+		return 0.0;
+	const long want = (n + 255) / 256;
+	const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+	hipLaunchKernelGGL(diff_norm2_kernel, dim3(grid), dim3(256), 0, s, x, y, n, dev_scratch);
+	BHIP_CHECK(hipGetLastError());
+	double h[1024];
+	BHIP_CHECK(hipMemcpyAsync(h, dev_scratch, sizeof(double) * grid, hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	double sum = 0.0;
+	for (unsigned i = 0; i < grid; i++)
+		sum += h[i];
+	return std::sqrt(sum);
+}
+
 void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s)
 {
 	if (n == 0)

@@ -17,7 +17,7 @@
 //
 // Knobs without a GPU meaning keep their place in the signatures: thread_chunk_size is accepted and
 // ignored; threadedfactor / threadedapply = false (the seq* / sf* / sap* factory types) select the exact
-// sequential result, obtained on the device by sweeping until the iterate is bitwise stationary.
+// sequential result, obtained on the device by level-scheduled exact passes.
 #pragma once
 
 #include <memory>
@@ -175,11 +175,12 @@ public:
 	explicit BJacobiSRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix);
 	virtual ~BJacobiSRPreconditioner();
 	index dim() const { return mat.nbrows * bs; }
-	bool relaxationAvailable() const { return false; }
+	bool relaxationAvailable() const { return true; }
 	PrecInfo compute();
 	void apply(const scalar *const r, scalar *const __restrict z) const;
-	/// the reference's Jacobi relaxation (src/solverops_jacobi.cpp:66-130) is not on the GPU path
-	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
+	/// synchronous Jacobi relaxation with the reference's optional convergence test on the step
+	/// difference (src/solverops_jacobi.cpp:66-119): solveparams.maxits, ctol, rtol, atol, dtol
+	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
 	void apply_device(const scalar *const dx, scalar *const dy) const;
 
 protected:

@@ -444,7 +444,8 @@ PetscErrorCode setup_localpreconditioner_blasted(KSP ksp, Blasted_data *const bc
 	ierr = PCShellSetDestroy(pc, &cleanup_blasted); CHKERRQ(ierr);
 	// the reference registers it for every type but ilu0 / cscbgs / none (src/blasted_petsc.cpp:711-718) and
 	// lets apply_relax throw where it is not implemented; here only the types whose relaxation exists
-	if (bctx->prectype == BLASTED_SGS || bctx->prectype == BLASTED_GS || bctx->prectype == BLASTED_LEVEL_SGS) {
+	if (bctx->prectype == BLASTED_SGS || bctx->prectype == BLASTED_GS || bctx->prectype == BLASTED_LEVEL_SGS ||
+	    bctx->prectype == BLASTED_JACOBI) {
 		ierr = PCShellSetApplyRichardson(pc, &relax_local_blasted); CHKERRQ(ierr);
 	}
 	return ierr;

@@ -231,10 +231,14 @@ void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
-void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const,
-                                                                   scalar *const __restrict) const
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const b,
+                                                                   scalar *const __restrict x) const
 {
-	throw std::runtime_error("Jacobi relaxation is not part of the MI355X backend (out of the hot path)");
+	if (!op)
+		throw std::runtime_error("Jacobi preconditioner: apply_relax() before compute()");
+	HipOperator::check(blasted_hip_jacobi_relax(op->get(), b, x, solveparams.maxits, solveparams.ctol ? 1 : 0,
+	                                            solveparams.rtol, solveparams.atol, solveparams.dtol, nullptr,
+	                                            BLASTED_HIP_HOST));
 }
 
 // ------------------------------------------------------------------------------- (block-)SGS

@@ -115,6 +115,13 @@ int blasted_hip_jacobi_compute(blasted_hip_prec p);
 /* BJacobiSRPreconditioner::apply, src/solverops_jacobi.cpp:51-63 */
 int blasted_hip_jacobi_apply(blasted_hip_prec p, const double *r, double *z, int loc);
 
+/* BJacobiSRPreconditioner::apply_relax, src/solverops_jacobi.cpp:66-119: at most maxits synchronous
+ * (block-)Jacobi steps on x (initial guess and result).  check_tol != 0: stop as the reference does on
+ * the step difference d_k = ||x_k+1 - x_k||_2: d_k < atol, d_k/d_0 < rtol or d_k/d_0 > dtol.
+ * steps_done (may be NULL) receives the number of steps taken. */
+int blasted_hip_jacobi_relax(blasted_hip_prec p, const double *b, double *x, int maxits, int check_tol,
+                             double rtol, double atol, double dtol, int *steps_done, int loc);
+
 /* Async[Block]SGS_SRPreconditioner::apply, src/solverops_sgs.cpp:47-83,149-176.
  * With INIT_A_NONE z is read as the initial guess of the backward sweeps (as in the reference). */
 int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int napplysweeps,

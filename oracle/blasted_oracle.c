@@ -826,6 +826,40 @@ void orc_gs_relax(const orc_bsr *m, const double *dblocks, int nsweeps, int chun
 	run_sweeps(m, relax_row_d, (const double *)&sv, b, x, nsweeps, chunk, mode, 0);
 }
 
+/* BJacobiSRPreconditioner::apply_relax, src/solverops_jacobi.cpp:66-119; returns the steps taken */
+int orc_jacobi_relax(const orc_bsr *m, const double *dblocks, int maxits, int ctol, double rtol,
+                     double atol, double dtol, const double *b, double *x)
+{
+	const long n = (long)m->nbrows * m->bs;
+	sgs_vals sv = {m->vals, dblocks};
+	double *xtemp = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+	double refdiffnorm = 1;
+	int step = 0;
+	for (; step < maxits; step++) {
+#pragma omp parallel for default(shared)
+		for (int i = 0; i < m->nbrows; i++)
+			relax_row_d(m, (const double *)&sv, i, b, x, xtemp);
+		if (ctol) {
+			double diffnorm = 0;
+			for (long i = 0; i < n; i++) {
+				const double diff = xtemp[i] - x[i];
+				diffnorm += diff * diff;
+				x[i] = xtemp[i];
+			}
+			diffnorm = sqrt(diffnorm);
+			if (step == 0)
+				refdiffnorm = diffnorm;
+			if (diffnorm < atol || diffnorm / refdiffnorm < rtol || diffnorm / refdiffnorm > dtol) {
+				step++;
+				break;
+			}
+		} else
+			memcpy(x, xtemp, sizeof(double) * (size_t)n);
+	}
+	free(xtemp);
+	return step;
+}
+
 /* ---------------------------------------------------------------- level scheduling */
 
 /* computeLevels, src/levelschedule.cpp:13-72.  levels[] receives the boundaries (levels[0] = 0,

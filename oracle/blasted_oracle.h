@@ -83,6 +83,11 @@ int orc_ilu0_apply(const orc_bsr *m, const double *iluvals, const double *scale,
 int orc_jacobi_compute(const orc_bsr *m, double *dblocks);
 void orc_jacobi_apply(const orc_bsr *m, const double *dblocks, const double *r, double *z);
 
+/* BJacobiSRPreconditioner::apply_relax, src/solverops_jacobi.cpp:66-119: synchronous Jacobi steps with the
+ * optional step-difference convergence test; returns the number of steps taken */
+int orc_jacobi_relax(const orc_bsr *m, const double *dblocks, int maxits, int ctol, double rtol,
+                     double atol, double dtol, const double *b, double *x);
+
 /* src/solverops_sgs.cpp:47-83 / :149-176.  In ORC_ASYNC_OMP the forward sweeps stay serial (the
  * reference's orphaned `omp for`, src/kernels/kernels_sgs.hpp:127), the backward ones are threaded. */
 void orc_sgs_apply(const orc_bsr *m, const double *dblocks, double *ytemp,

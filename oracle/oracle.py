@@ -156,6 +156,19 @@ def jacobi_apply(m, dblocks, r):
     return z
 
 
+def jacobi_relax(m, dblocks, b, x0=None, maxits=1, ctol=False, rtol=0.0, atol=0.0, dtol=1e300):
+    """-> (x, steps taken); src/solverops_jacobi.cpp:66-119."""
+    M = _Mat(m)
+    d, b = _f64(dblocks), _f64(b)
+    x = np.zeros(M.n) if x0 is None else _f64(x0).copy()
+    lib().orc_jacobi_relax.restype = C.c_int
+    lib().orc_jacobi_relax.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, C.c_void_p, C.c_void_p]
+    steps = lib().orc_jacobi_relax(M.ref, _ptr(d), int(maxits), int(bool(ctol)), float(rtol), float(atol),
+                                   float(dtol), _ptr(b), _ptr(x))
+    return x, int(steps)
+
+
 def sgs_apply(m, dblocks, r, napplysweeps=1, chunk=256, mode=GS_SERIAL, init=INIT_A_ZERO, z0=None,
               y0=None, return_y=False):
     M = _Mat(m)

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle's OpenMP regions are entered thousands of times on tiny matrices; with one thread per
+# hardware thread of a large host (the GPU boxes report 128 but grant a share of them) the fork/join
+# barriers dominate.  A modest team keeps the checker fast; bench.py's cpu_baseline is not affected.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -486,3 +486,33 @@ def test_sequential_variants_are_exact(golden, case):
     zs = p.sgs_apply(r, -1, init=capi.INIT_A_ZERO)
     assert rel(zs, O.sgs_apply(m, p.get_dblocks(), r, 1, mode=O.GS_SERIAL)) < TOL_EXACT
     p.close()
+
+
+# ---------------------------------------------------------------------------- Jacobi relaxation
+
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "msc_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4"])
+def test_jacobi_relaxation_matches_oracle(golden, case):
+    """BJacobiSRPreconditioner::apply_relax, src/solverops_jacobi.cpp:66-119: synchronous steps, with and
+    without the convergence test on the step difference (same stopping step as the oracle)."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    b = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    x0 = 0.1 * np.sin(np.arange(n))
+    x = x0.copy()
+    assert p.jacobi_relax(b, x, 4) == 4
+    want, steps = O.jacobi_relax(m, gd, b, x0=x0, maxits=4)
+    assert steps == 4
+    if np.all(np.isfinite(want)) and np.abs(want).max() < 1e8:
+        assert rel(x, want) < 1e-11
+    # convergence test: relative tolerance reached (or divergence detected) at the same step
+    for rtol, dtol in ((0.3, 1e300), (0.0, 1.5)):
+        x = np.zeros(n)
+        got_steps = p.jacobi_relax(b, x, 200, check_tol=True, rtol=rtol, atol=0.0, dtol=dtol)
+        want, steps = O.jacobi_relax(m, gd, b, maxits=200, ctol=True, rtol=rtol, atol=0.0, dtol=dtol)
+        assert got_steps == steps
+        if np.all(np.isfinite(want)) and np.abs(want).max() < 1e8:
+            assert rel(x, want) < 1e-9
+    p.close()
