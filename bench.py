@@ -49,6 +49,10 @@ def cpu_baseline(op, nsample, bs, sweeps, full_unit_bytes, units_per_call, budge
     os.environ.setdefault("OMP_PLACES", "cores")
     import oracle
     from blasted_amd import workloads
+    # one thread per CPU this process is really granted (affinity mask cut by the cgroup quota): more
+    # threads than that only thrash; the count is what `cores` reports
+    budget = oracle.cpu_budget()
+    oracle.set_num_threads(budget)
     m = workloads.poisson3d(nsample + 2, bs, grid="uniform")
     r = workloads.rhs_vector(m["nbrows"] * bs)
     kw = {}
@@ -69,8 +73,9 @@ def cpu_baseline(op, nsample, bs, sweeps, full_unit_bytes, units_per_call, budge
         "unit": "sweeps/s", "cores": oracle.num_threads(), "kind": "port",
         "achieved_gbps": sample_unit * units_per_call / t / 1e9,
         "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) %s on Poisson %d^3 bs=%d, %d sweeps per call, "
-                  "min of %d calls = %.1f ms; scaled to the full size by algorithmic bytes" %
-                  (op, nsample, bs, sweeps, reps, t * 1e3),
+                  "min of %d calls = %.1f ms, %d OpenMP threads = the CPUs granted to this process (%d hardware "
+                  "threads visible); scaled to the full size by algorithmic bytes" %
+                  (op, nsample, bs, sweeps, reps, t * 1e3, oracle.num_threads(), os.cpu_count() or 0),
     }
 
 

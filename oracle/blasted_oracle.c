@@ -24,6 +24,12 @@ int orc_num_threads(void)
 #endif
 }
 
+void orc_set_num_threads(int n)
+{
+	if (n > 0)
+		omp_set_num_threads(n);
+}
+
 /* ---------------------------------------------------------------- dense block helpers */
 
 /* entry (r,c) of a block */

@@ -53,6 +53,7 @@ enum { ORC_INIT_F_ZERO = 0, ORC_INIT_F_ORIGINAL = 1, ORC_INIT_F_SGS = 2, ORC_INI
 enum { ORC_INIT_A_ZERO = 0, ORC_INIT_A_JACOBI = 1, ORC_INIT_A_NONE = 2 };
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 /* src/ilu_pattern.cpp:32-163.  count: fills posptr[nnzb+1], returns total pairs.  */
 long orc_ilu_positions_count(const orc_bsr *m, int *posptr);

@@ -49,6 +49,31 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def cpu_budget():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota (cpu.max) -- a
+    container that sees 256 hardware threads may be granted 16 CPUs' worth of time."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _i32(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a
