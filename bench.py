@@ -227,7 +227,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "kernel": "sweep_kernel (%s sweep)" % ("descending/upper" if kernel == "upper" else "ascending/lower"),
+                         "kernel": "%s (%s pass; bhip::sweepw_kernel<%d, ...> in the rocprofv3 summaries)" % (
+                             {"ilu_apply": "upper triangular sweep z <- D^-1 (y - U z)",
+                              "sgs_apply": "backward Gauss-Seidel sweep z <- y - D^-1 U z",
+                              "sgs_relax": "relaxation pass x <- D^-1 (b - (A - D) x)", "spmv": "BSR SpMV",
+                              "factor": "ILU(0) fixed-point sweep (bhip::factor4_kernel)"}[args.op],
+                             "descending" if kernel == "upper" else "ascending", bs),
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes,
                          "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
                          "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
