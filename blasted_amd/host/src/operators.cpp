@@ -45,6 +45,21 @@ int HipOperator::default_device()
 
 int HipOperator::sweep_mode()
 {
+	// BLASTED_HIP_EXACT_APPLY=1: the application of every asynchronous type (ilu0, sgs) runs as exact
+	// level-scheduled passes -- the limit the sweeps converge to, cheaper than three of them on this GPU
+	// and, unlike a few Jacobi-like sweeps of thousands of concurrent waves, as accurate as the
+	// reference's nearly sequential threaded sweeps ("End to end").  Factorisation and the
+	// relaxations keep their asynchronous form.
+	const char *x = std::getenv("BLASTED_HIP_EXACT_APPLY");
+	if (x && std::atoi(x) != 0)
+		return BLASTED_HIP_LEVEL;
+	const char *e = std::getenv("BLASTED_HIP_SYNC_SWEEPS");
+	return (e && std::atoi(e) != 0) ? BLASTED_HIP_JACOBI_SYNC : BLASTED_HIP_ASYNC;
+}
+
+// the mode for entry points that do not take LEVEL (factorisation) or must stay asynchronous
+static int async_or_sync_mode()
+{
 	const char *e = std::getenv("BLASTED_HIP_SYNC_SWEEPS");
 	return (e && std::atoi(e) != 0) ? BLASTED_HIP_JACOBI_SYNC : BLASTED_HIP_ASYNC;
 }
@@ -291,7 +306,7 @@ void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const 
 	if (!op)
 		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
 	// maxits steps; tolerances are never checked for SGS (src/solverops_sgs.cpp:96-115)
-	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, HipOperator::sweep_mode(),
+	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, detail::async_or_sync_mode(),
 	                                         BLASTED_HIP_HOST));
 }
 
@@ -302,7 +317,7 @@ void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax_device
 	if (!op)
 		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
 	HipOperator::check(blasted_hip_sgs_relax(op->get(), db, dx, solveparams.maxits,
-	                                         HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+	                                         detail::async_or_sync_mode(), BLASTED_HIP_DEVICE));
 }
 
 // ------------------------------------------------------------------------------- chaotic relaxation (gs)
@@ -321,7 +336,7 @@ void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply(const scalar *const 
 {
 	if (!op)
 		throw std::runtime_error("chaotic relaxation: apply() before compute()");
-	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, napplysweeps, HipOperator::sweep_mode(),
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, napplysweeps, detail::async_or_sync_mode(),
 	                                        BLASTED_HIP_HOST));
 }
 
@@ -331,7 +346,7 @@ void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply_relax(const scalar *
 {
 	if (!op)
 		throw std::runtime_error("chaotic relaxation: apply_relax() before compute()");
-	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, solveparams.maxits, HipOperator::sweep_mode(),
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, solveparams.maxits, detail::async_or_sync_mode(),
 	                                        BLASTED_HIP_HOST));
 }
 
@@ -363,7 +378,7 @@ PrecInfo AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::compute()
 	// sequential variants (seqilu0 / sfilu0): sweep until stationary = the exact serial factorisation
 	const int sweeps = threadedfactor ? nbuildsweeps : BLASTED_SEQUENTIAL_SYMBOL;
 	HipOperator::check(blasted_hip_ilu0_factorize(op->get(), sweeps, (int)factinittype, usescaling ? 1 : 0,
-	                                              HipOperator::sweep_mode(),
+	                                              detail::async_or_sync_mode(),
 	                                              compute_remainder ? info.f_info.data() : nullptr));
 	return info;
 }

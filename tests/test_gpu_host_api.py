@@ -52,6 +52,23 @@ def test_native_solve(name, mat, extra, tol, testtol, maxiter):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_exact_apply_switch():
+    """BLASTED_HIP_EXACT_APPLY=1: the `ilu0` type with ONE asynchronous apply sweep -- far too few for this
+    matrix -- converges like the exact variants, because its application runs as exact passes."""
+    base = [DRIVER, "--fact_init_type", "init_original", "--apply_init_type", "init_zero",
+            "--mat_file", os.path.join(G, "2dcyl1.mtx"), "--b_file", os.path.join(G, "2dcyl1_b.mtx"),
+            "--x_file", os.path.join(G, "2dcyl1_x.mtx"), "--solver_tol", "1e-12", "--test_tol", "1e-8",
+            "--max_iter", "60", "--preconditioner_type", "ilu0", "--mat_type", "bsr", "--build_sweeps", "30",
+            "--apply_sweeps", "1"]
+    env = dict(os.environ)
+    env.pop("BLASTED_HIP_EXACT_APPLY", None)
+    r0 = subprocess.run(base, capture_output=True, text=True, timeout=300, env=env)
+    env["BLASTED_HIP_EXACT_APPLY"] = "1"
+    r1 = subprocess.run(base, capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert r0.returncode != 0   # one asynchronous sweep does not get there in 60 iterations
+
+
 def test_factory_rejects_out_of_scope_types():
     args = [DRIVER, "--preconditioner_type", "cscbgs", "--mat_type", "csr",
             "--mat_file", os.path.join(G, "2dcyl1.mtx"), "--b_file", os.path.join(G, "2dcyl1_b.mtx")]
