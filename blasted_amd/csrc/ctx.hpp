@@ -67,6 +67,7 @@ struct SweepArgs {
 	double *xout;           // written iterate (== xin for in-place async sweeps)
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
+	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
 };
 
 // Level schedule of a pattern (kernels_level.hip): rows sorted by dependency depth

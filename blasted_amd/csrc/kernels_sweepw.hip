@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 		bool ok[UNR];
 #pragma unroll
 		for (int u = 0; u < UNR; u++) {
-			const int ls = (step0 + u) * RSTEP + wave * RPW + g;  // position in sweep order
+			// position in sweep order.  Interleaved: the rows one step computes side by side are NSTEPS apart,
+			// so a row's predecessor in the sweep belongs to the step before (already stored) instead of to
+			// the same step (stale): the in-place sweep is Gauss-Seidel-like along the chunk, not Jacobi-like.
+			constexpr int NSTEPS = RCHUNK / RSTEP;
+			const int slotpos = wave * RPW + g;
+			const int ls = a.interleave ? slotpos * NSTEPS + (step0 + u) : (step0 + u) * RSTEP + slotpos;
 			ok[u] = ls < rc;
 			const int lr = ok[u] ? (a.descending ? rc - 1 - ls : ls) : 0;
 			lrow[u] = lr;

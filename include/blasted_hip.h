@@ -186,6 +186,8 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
  * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":
  * exact triangular solves read level-ordered copies of the factor's triangles (one extra copy of the
  * factor, permuted once per factorisation) or the factor in place (environment: BLASTED_HIP_LEVELSTORE);
+ * "interleave=1": interleaved row order inside a chunk for the in-place sweeps (better sweep quality,
+ * 14 % slower; default 0).
  * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
  * factor's triangles (one more copy of the factor, one copy pass per factorisation) or the factor in
  * place (environment: BLASTED_HIP_COMPACT).
