@@ -449,3 +449,45 @@ def test_coo_to_bsr_matches_reference_block_coo_fixture(golden):
     assert np.array_equal(np.repeat(np.arange(nbr), np.diff(browptr)), brow)
     assert vals.size == nnzb * 9 and np.array_equal(m["vals"], vals)
     assert np.array_equal(m["diagind"], diagind)
+
+
+@pytest.mark.parametrize("bs,rowmajor", [(1, False), (4, False), (4, True)])
+def test_gs_and_jacobi_relaxation_are_textbook(golden, bs, rowmajor):
+    """What the reference's `issame` relaxation tests pin against PETSc (tests/CMakeLists.txt:291-317:
+    pbjacobi <-> jacobi, forward SOR <-> gs): with one thread a `gs` sweep is a forward (block) Gauss-Seidel
+    sweep and a Jacobi step is x <- D^-1 (b - (A - D) x), written here with dense algebra."""
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), bs, rowmajor)
+    A = mtxio.bsr_to_scipy(m).toarray()
+    n = A.shape[0]
+    rowb = np.arange(n)[:, None] // bs
+    colb = np.arange(n)[None, :] // bs
+    D = np.where(rowb == colb, A, 0.0)
+    L = np.where(colb < rowb, A, 0.0)
+    U = np.where(colb > rowb, A, 0.0)
+    b = W.rhs_vector(n)
+    d = O.jacobi_compute(m)
+    x0 = 0.3 * np.cos(np.arange(n))
+    # gs: three forward sweeps
+    want = x0.copy()
+    for _ in range(3):
+        want = np.linalg.solve(D + L, b - U @ want)
+    got = O.gs_relax(m, d, b, x0=x0, nsweeps=3, mode=O.GS_SERIAL)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-10
+    # jacobi: three synchronous steps, and the convergence test stops where the dense iteration does
+    want = x0.copy()
+    for _ in range(3):
+        want = np.linalg.solve(D, b - (A - D) @ want)
+    got, steps = O.jacobi_relax(m, d, b, x0=x0, maxits=3)
+    assert steps == 3 and np.abs(got - want).max() / np.abs(want).max() < 1e-10
+    xk, ref, k = np.zeros(n), None, 0
+    for k in range(1, 201):
+        xn = np.linalg.solve(D, b - (A - D) @ xk)
+        dn = np.linalg.norm(xn - xk)
+        xk = xn
+        ref = dn if ref is None else ref
+        if dn / ref < 0.5 or dn / ref > 1e6:
+            break
+    got, steps = O.jacobi_relax(m, d, b, maxits=200, ctol=True, rtol=0.5, atol=0.0, dtol=1e6)
+    assert steps == k
+    if np.all(np.isfinite(xk)):
+        assert np.abs(got - xk).max() / np.abs(xk).max() < 1e-9
