@@ -30,6 +30,10 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def mtxio_vec(golden, name):
+    return mtxio.read_mtx_dense(G(golden, name))
+
+
 def make_prec(m):
     p = capi.Prec(0)
     p.set_matrix(m)
@@ -515,4 +519,34 @@ def test_jacobi_relaxation_matches_oracle(golden, case):
         assert got_steps == steps
         if np.all(np.isfinite(want)) and np.abs(want).max() < 1e8:
             assert rel(x, want) < 1e-9
+    p.close()
+
+
+# ---------------------------------------------------------------------------- iteration counts (compare_its)
+
+@pytest.mark.parametrize("prec", ["sgs_1_8", "ilu0_4_8", "ilu0_4_8_scaled"])
+def test_async_preconditioning_iteration_counts(golden, prec):
+    """The reference's `compare_its` tests (tests/CMakeLists.txt:374-401, input/asyncpreconditioning.perc):
+    Richardson on 2dcyl1 (bs=4) to rtol 1e-5 within 200 iterations, preconditioned by asynchronous SGS with
+    (1,8) sweeps / ILU(0) with (4,8) sweeps, needs the iteration count of the exact SGS / ILU(0) to 1 %."""
+    from krylov import richardson
+    m = matrices(golden)["2dcyl1_bs4_col"]()
+    n = m["nbrows"] * 4
+    b = mtxio_vec(golden, "2dcyl1_b.mtx")
+    p = make_prec(m)
+    A = lambda v: p.spmv(v)
+    if prec.startswith("sgs"):
+        p.jacobi_compute()
+        M_async = lambda v: p.sgs_apply(v, 8, init=capi.INIT_A_ZERO, mode=capi.ASYNC)
+        M_exact = lambda v: p.sgs_apply(v, 1, mode=capi.LEVEL)
+        x, its_async, rel_a = richardson(A, M_async, b, 1e-5, 200)
+        x, its_exact, rel_e = richardson(A, M_exact, b, 1e-5, 200)
+    else:
+        sc = prec.endswith("scaled")
+        p.ilu0_factorize(4, init=capi.INIT_F_ORIGINAL, usescale=sc, mode=capi.ASYNC)
+        x, its_async, rel_a = richardson(A, lambda v: p.ilu0_apply(v, 8, mode=capi.ASYNC), b, 1e-5, 200)
+        p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL, usescale=sc)
+        x, its_exact, rel_e = richardson(A, lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL), b, 1e-5, 200)
+    assert rel_a < 1e-5 and rel_e < 1e-5 and its_exact < 200
+    assert abs(its_async - its_exact) <= max(1, round(0.01 * its_exact)), (its_async, its_exact)
     p.close()
