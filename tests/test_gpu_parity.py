@@ -550,3 +550,33 @@ def test_async_preconditioning_iteration_counts(golden, prec):
     assert rel_a < 1e-5 and rel_e < 1e-5 and its_exact < 200
     assert abs(its_async - its_exact) <= max(1, round(0.01 * its_exact)), (its_async, its_exact)
     p.close()
+
+
+def test_async_relaxation_convergence_and_bound(golden):
+    """The reference's relaxation tests on 2dcyl1 bs=4 (tests/CMakeLists.txt:357-372, input/
+    asyncrelaxation.perc): outer Richardson to rtol 1e-5 within 200 iterations whose inner solve is 10
+    relaxation iterations from a zero guess.  `convergence`: the asynchronous `gs` relaxation gets there;
+    `upper_bound_its`: asynchronous SGS relaxation needs fewer outer iterations than block-Jacobi."""
+    from krylov import richardson
+    m = matrices(golden)["2dcyl1_bs4_col"]()
+    n = m["nbrows"] * 4
+    b = mtxio_vec(golden, "2dcyl1_b.mtx")
+    p = make_prec(m)
+    p.jacobi_compute()
+    A = lambda v: p.spmv(v)
+
+    def inner(kind):
+        def M(v):
+            x = np.zeros(n)
+            if kind == "jacobi":
+                p.jacobi_relax(v, x, 10)
+            elif kind == "gs":
+                p.gs_relax(v, x, 10, mode=capi.ASYNC)
+            else:
+                p.sgs_relax(v, x, 10, mode=capi.ASYNC)
+            return x
+        return M
+    res = {k: richardson(A, inner(k), b, 1e-5, 200) for k in ("jacobi", "gs", "sgs")}
+    assert res["gs"][2] < 1e-5 and res["gs"][1] < 200          # convergence
+    assert res["sgs"][2] < 1e-5 and res["sgs"][1] < res["jacobi"][1]   # upper_bound_its
+    p.close()
