@@ -248,9 +248,58 @@ static bool level_view(blasted_hip_prec p, bool upper, LevelView &v, const doubl
 	v.meta = upper ? ls.umeta : ls.lmeta;
 	v.ptr = upper ? ls.uptr : ls.lptr;
 	v.head = upper ? ls.uhead : ls.lhead;
+	v.headp = upper ? ls.uheadp : ls.lheadp;
+	v.colp = upper ? ls.ucolp : ls.lcolp;
 	v.bcolind = upper ? ls.ucol : ls.lcol;
 	v.vals = upper ? c.u : c.l;
 	return true;
+}
+
+static int g_level_perm = 1;  // tuning: exact ILU solves keep their iterate level-ordered (bs 4/8 column-major)
+
+// ytemp in natural order again (after an exact apply that kept y level-ordered)
+static void restore_ytemp(blasted_hip_prec p)
+{
+	if (p->y_in_level_order) {
+		launch_level_unpermute(p->levels, p->pat.bs, p->yperm, p->ytemp, p->stream);
+		p->y_in_level_order = false;
+	}
+}
+
+// The exact ILU solves with a level-ordered iterate (kernels_levelw.hip, PERM): the lower solve leaves y in
+// p->yperm, the upper solve reads it there, gathers from p->zperm and also writes z in natural order to x.
+// Returns 0 when this form does not apply (the caller continues with the natural-order forms).
+static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, double *x, LevelSchedule &ls,
+                               const LevelView &view)
+{
+	if (!g_level_perm || !syncfree_wide_supported(p->pat))
+		return 0;
+	if (upper && !p->y_in_level_order)
+		return 0;
+	const long n = p->n();
+	double *out = upper ? ensure(p->zperm, n) : ensure(p->yperm, n);
+	launch_syncfree_fill(out, n, p->stream);
+	a.vals = view.vals;
+	a.xin = out;
+	a.xout = out;
+	a.xnat = upper ? x : nullptr;
+	if (upper)
+		a.rhs = p->yperm;
+	if (!launch_syncfree_wide(a, upper, ls, view.ptr, view.colp, view.headp, p->stream, true))
+		return 0;
+	int ctl[2] = {0, 0};
+	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, p->stream));
+	BHIP_CHECK(hipStreamSynchronize(p->stream));
+	ls.sf_launches++;
+	if (ctl[1]) {
+		ls.sf_aborts++;
+		if (upper)
+			restore_ytemp(p);  // the natural-order forms below read y from ytemp
+		return 0;
+	}
+	if (!upper)
+		p->y_in_level_order = true;
+	return 2;
 }
 
 // One exact in-order pass of an operator producing `x` (for relaxation: from the previous iterate
@@ -267,6 +316,17 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 			use_view = level_view(p, part == PART_UPPER, view, p->iluvals, p->fac_lvl);
 		else if (triangular && a.vals == p->vals)
 			use_view = level_view(p, part == PART_UPPER, view, p->vals, p->mat_lvl);
+		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
+		const bool ilu_upper = part == PART_UPPER && post == POST_D_SUB && dsrc == D_VALS_DIAG;
+		if (use_view && a.vals == p->iluvals && (ilu_lower || ilu_upper)) {
+			if (ilu_lower)
+				p->y_in_level_order = false;
+			const int done = exact_pass_permuted(p, a, ilu_upper, x, ls, view);
+			if (done)
+				return done;
+			if (ilu_upper)
+				restore_ytemp(p);
+		}
 		launch_syncfree_fill(x, p->n(), p->stream);
 		a.xin = xold ? xold : x;
 		a.xout = x;
@@ -412,6 +472,8 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		dev_free(p->finv);
 		dev_free(p->scale);
 		dev_free(p->ytemp);
+		dev_free(p->yperm);
+		dev_free(p->zperm);
 		dev_free(p->dblocks);
 		for (int i = 0; i < 3; i++) {
 			dev_free(p->tmp[i]);
@@ -712,6 +774,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		double *dz = out_vec(p, z, loc, 1);
 		const bool scalar = p->pat.bs == 1;
 		const bool jac = mode == BLASTED_HIP_JACOBI_SYNC;
+		p->y_in_level_order = false;  // this call rewrites ytemp
 
 		// y := 0 (both init types), src/solverops_ilu0.cpp:83-94.  The prologue z := S r is fused: the
 		// lower sweeps read r (times scale) directly as their right-hand side.
@@ -864,6 +927,7 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 				BHIP_CHECK(hipMemcpyAsync(dz, z, nbytes, hipMemcpyHostToDevice, p->stream));
 		}
 		const bool reinit = apply_init == BLASTED_HIP_INIT_A_JACOBI || apply_init == BLASTED_HIP_INIT_A_ZERO;
+		p->y_in_level_order = false;  // this call rewrites ytemp
 		if (reinit) {  // src/solverops_sgs.cpp:57-60
 			Phase ph(p, 2);
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
@@ -1162,6 +1226,14 @@ int blasted_hip_get_scale(blasted_hip_prec p, double *out)
 
 int blasted_hip_get_ytemp(blasted_hip_prec p, double *out)
 {
+	if (p && p->y_in_level_order) {  // the last exact apply kept y level-ordered: natural order on demand
+		const int rc = guarded([&] {
+			use_device(p);
+			restore_ytemp(p);
+		});
+		if (rc != BLASTED_HIP_OK)
+			return rc;
+	}
 	return get_array(p, p ? p->ytemp : nullptr, p ? p->n() : 0, out, "ytemp");
 }
 
@@ -1219,7 +1291,9 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 int blasted_hip_set_tuning(const char *spec)
 {
 	return guarded([&] {
-		if (spec && std::strncmp(spec, "interleave=", 11) == 0)
+		if (spec && std::strncmp(spec, "levelperm=", 10) == 0)
+			g_level_perm = spec[10] != '0';
+		else if (spec && std::strncmp(spec, "interleave=", 11) == 0)
 			g_interleave = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "compact=", 8) == 0)
 			g_compact = spec[8] != '0';

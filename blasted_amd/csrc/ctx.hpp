@@ -65,6 +65,7 @@ struct SweepArgs {
 	const double *rscale;   // optional elementwise factor on rhs (z = S r fused into the sweep)
 	const double *xin;      // gathered iterate
 	double *xout;           // written iterate (== xin for in-place async sweeps)
+	double *xnat;           // level-ordered exact solves: optional second output in natural row order
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
 	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
@@ -93,6 +94,10 @@ struct LevelSchedule {
 	int *lcol = nullptr, *ucol = nullptr;    // device, nnzL / nnzU + nbrows
 	int4 *lmeta = nullptr, *umeta = nullptr; // device, nbrows: {row, lptr[p], lptr[p+1], -} / {row, -, uptr[p], uptr[p+1]}
 	int4 *lhead = nullptr, *uhead = nullptr; // device, 2 * nbrows: column indices of a position's first 8 blocks (-1: none)
+	// the same indices as POSITIONS in the level order (exact solves that keep their iterate level-ordered)
+	int *posof = nullptr;                      // device, nbrows: position of each row
+	int *lcolp = nullptr, *ucolp = nullptr;    // device: lcol / ucol mapped through posof
+	int4 *lheadp = nullptr, *uheadp = nullptr; // device, 2 * nbrows: lhead / uhead mapped through posof
 	long nnz_lower = 0, nnz_dupper = 0;
 };
 
@@ -100,6 +105,8 @@ struct LevelSchedule {
 struct LevelView {
 	const int4 *meta = nullptr;
 	const int4 *head = nullptr;
+	const int4 *headp = nullptr;  // head as positions
+	const int *colp = nullptr;    // column indices as positions
 	const int *ptr = nullptr;
 	const int *bcolind = nullptr;
 	const double *vals = nullptr;
@@ -141,7 +148,9 @@ bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
                            hipStream_t s, const LevelView *view = nullptr);
 // kernels_levelw.hip (streaming exact triangular pass, column-major bs 4 / 8, level-ordered copies)
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          const int4 *head, hipStream_t s);
+                          const int4 *head, hipStream_t s, bool permuted = false);
+bool syncfree_wide_supported(const Pattern &pat);
+void launch_level_unpermute(const LevelSchedule &ls, int bs, const double *xperm, double *xnat, hipStream_t s);
 void set_levelw_enabled(int on);
 void set_syncfree_one_step(int on);
 void build_natural_storage(const Pattern &pat, LevelSchedule &ns, hipStream_t s);
@@ -223,6 +232,8 @@ struct blasted_hip_prec_s {
 		double *l = nullptr, *u = nullptr;
 		bool valid = false;
 	};
+	double *yperm = nullptr, *zperm = nullptr;  // level-ordered iterates of the exact ILU solves
+	bool y_in_level_order = false;              // yperm holds L^-1 r of the last exact apply, ytemp is stale
 	bhip::LevelSchedule natstore;  // natural-order compact triangle storage (pattern part)
 	TriCopy fac_nat, fac_lvl, mat_nat, mat_lvl;
 

@@ -508,10 +508,29 @@ __global__ __launch_bounds__(256) void level_counts_kernel(const Pattern pat, co
 	cu[k] = pat.browptr[row + 1] - dg;
 }
 
+__global__ __launch_bounds__(256) void level_posof_kernel(const int *rows, int n, int *posof)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n)
+		posof[rows[k]] = k;
+}
+
+// x_nat[row] = x_perm[position of row], one double per thread
+__global__ __launch_bounds__(256) void level_unpermute_kernel(const int *rows, long n, int bs, const double *xperm,
+                                                              double *xnat)
+{
+	const long i = (long)blockIdx.x * 256 + threadIdx.x;
+	if (i < n * bs) {
+		const long p = i / bs;
+		xnat[(long)rows[p] * bs + (i - p * bs)] = xperm[i];
+	}
+}
+
 // column indices in level order + the descriptors of the two copies
 __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, const int *rows, const int *lptr,
                                                          const int *uptr, int *lcol, int *ucol, int4 *lmeta,
-                                                         int4 *umeta, int4 *lhead, int4 *uhead)
+                                                         int4 *umeta, int4 *lhead, int4 *uhead, const int *posof,
+                                                         int *lcolp, int *ucolp, int4 *lheadp, int4 *uheadp)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
 	if (k >= pat.nbrows)
@@ -519,10 +538,14 @@ __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, cons
 	const int row = rows[k];
 	const int rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
 	const int l0 = lptr[k], u0 = uptr[k];
-	for (int jj = rp0; jj < dg; jj++)
+	for (int jj = rp0; jj < dg; jj++) {
 		lcol[l0 + (jj - rp0)] = pat.bcolind[jj];
-	for (int jj = dg; jj < rp1; jj++)
+		lcolp[l0 + (jj - rp0)] = posof[pat.bcolind[jj]];
+	}
+	for (int jj = dg; jj < rp1; jj++) {
 		ucol[u0 + (jj - dg)] = pat.bcolind[jj];
+		ucolp[u0 + (jj - dg)] = posof[pat.bcolind[jj]];
+	}
 	lmeta[k] = make_int4(row, l0, l0 + (dg - rp0), 0);
 	umeta[k] = make_int4(row, 0, u0, u0 + (rp1 - dg));
 	// the first eight column indices of each copy, addressable from the position alone (two int4 each)
@@ -535,6 +558,14 @@ __global__ __launch_bounds__(256) void level_cols_kernel(const Pattern pat, cons
 	lhead[2 * k + 1] = make_int4(hl[4], hl[5], hl[6], hl[7]);
 	uhead[2 * k] = make_int4(hu[0], hu[1], hu[2], hu[3]);
 	uhead[2 * k + 1] = make_int4(hu[4], hu[5], hu[6], hu[7]);
+	for (int q = 0; q < 8; q++) {
+		hl[q] = hl[q] >= 0 ? posof[hl[q]] : -1;
+		hu[q] = hu[q] >= 0 ? posof[hu[q]] : -1;
+	}
+	lheadp[2 * k] = make_int4(hl[0], hl[1], hl[2], hl[3]);
+	lheadp[2 * k + 1] = make_int4(hl[4], hl[5], hl[6], hl[7]);
+	uheadp[2 * k] = make_int4(hu[0], hu[1], hu[2], hu[3]);
+	uheadp[2 * k + 1] = make_int4(hu[4], hu[5], hu[6], hu[7]);
 }
 
 // values of the two triangles into level order: 16 lanes move one row, 8 bytes per lane and step
@@ -587,7 +618,8 @@ void free_level_schedule(LevelSchedule &ls)
 	if (ls.ctl)
 		(void)hipFree(ls.ctl);
 	for (void *q : {(void *)ls.lptr, (void *)ls.uptr, (void *)ls.lcol, (void *)ls.ucol, (void *)ls.lmeta,
-	                (void *)ls.umeta, (void *)ls.lhead, (void *)ls.uhead})
+	                (void *)ls.umeta, (void *)ls.lhead, (void *)ls.uhead, (void *)ls.posof, (void *)ls.lcolp,
+	                (void *)ls.ucolp, (void *)ls.lheadp, (void *)ls.uheadp})
 		if (q)
 			(void)hipFree(q);
 	ls = LevelSchedule();
@@ -801,8 +833,15 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		ls.umeta = lvl_alloc<int4>(n);
 		ls.lhead = lvl_alloc<int4>(2 * (size_t)n);
 		ls.uhead = lvl_alloc<int4>(2 * (size_t)n);
+		ls.posof = lvl_alloc<int>(n);
+		ls.lcolp = lvl_alloc<int>((size_t)ls.nnz_lower);
+		ls.ucolp = lvl_alloc<int>((size_t)ls.nnz_dupper);
+		ls.lheadp = lvl_alloc<int4>(2 * (size_t)n);
+		ls.uheadp = lvl_alloc<int4>(2 * (size_t)n);
+		hipLaunchKernelGGL(level_posof_kernel, dim3(grid), dim3(256), 0, s, ls.rows, n, ls.posof);
 		hipLaunchKernelGGL(level_cols_kernel, dim3(grid), dim3(256), 0, s, pat, ls.rows, ls.lptr, ls.uptr, ls.lcol,
-		                   ls.ucol, ls.lmeta, ls.umeta, ls.lhead, ls.uhead);
+		                   ls.ucol, ls.lmeta, ls.umeta, ls.lhead, ls.uhead, ls.posof, ls.lcolp, ls.ucolp, ls.lheadp,
+		                   ls.uheadp);
 		BHIP_CHECK(hipGetLastError());
 		BHIP_CHECK(hipStreamSynchronize(s));
 		ls.storage_built = true;
@@ -815,6 +854,16 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 	for (void *q : {(void *)cl, (void *)cu, tmp})
 		if (q)
 			(void)hipFree(q);
+}
+
+void launch_level_unpermute(const LevelSchedule &ls, int bs, const double *xperm, double *xnat, hipStream_t s)
+{
+	const long n = (long)ls.count * bs;
+	if (n == 0)
+		return;
+	hipLaunchKernelGGL(level_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ls.rows,
+	                   (long)ls.count, bs, xperm, xnat);
+	BHIP_CHECK(hipGetLastError());
 }
 
 // The same compact two-triangle storage in NATURAL row order (rows = identity): the asynchronous sweeps

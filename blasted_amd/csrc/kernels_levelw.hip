@@ -65,7 +65,15 @@ struct LWGeo {
 // A workgroup is UNR row steps, all requested at once.  Dependent chain of a row: {block pointers, row
 // number, its first four column indices (head)} -> {blocks, right-hand side, polled iterate entries} ->
 // result; no LDS, no workgroup barrier.
-template <int BS, bool UPPER, int UNR>
+// PERM: the iterate being produced (a.xout) is LEVEL-ORDERED -- entry block p belongs to position p -- and
+// `cols` / `head` hold positions.  A row's own result is then contiguous with its neighbours' in the
+// sweep, and the entries it gathers lie in the few levels before it: natural-order vectors cost a
+// scattered 32-byte DRAM burst per gather, which was what bounded this pass.  The lower solve reads its
+// right-hand side r by row number and writes y level-ordered; the upper solve reads that y by position
+// and writes z both level-ordered (for its own gathers) and, through a.xnat, in natural order.  Gathers
+// look through the caches first: an entry is written once after the fill, so anything but "pending" is
+// final wherever it is read from; a (possibly stale) "pending" is re-read coherently.
+template <int BS, bool UPPER, int UNR, bool PERM>
 __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *__restrict__ ptr,
                                                   const int *__restrict__ cols, const int4 *__restrict__ head,
                                                   const int *__restrict__ rows, const int count, int *ctl)
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 	const int gbase = lane & ~(G - 1);
 	const bool desc = a.descending != 0;
 
-	int row[UNR], jbeg[UNR], jend[UNR];
+	int row[UNR], pp[UNR], jbeg[UNR], jend[UNR];
 	int4 hd[UNR];
 	bool ok[UNR];
 #pragma unroll
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 		ok[u] = pos < count;
 		const int p = ok[u] ? (int)(desc ? count - 1 - pos : pos) : 0;
 		row[u] = rows[p];
+		pp[u] = p;
 		jbeg[u] = ok[u] ? ptr[p] : 0;
 		jend[u] = ok[u] ? ptr[p + 1] : 0;
 		hd[u] = head[2 * p];  // the first four of the eight head entries
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 					const int idx = slot + k * NB;  // item number inside the row part: its column is in the head
 					const int col = idx == 0 ? hd[u].x : (idx == 1 ? hd[u].y : (idx == 2 ? hd[u].z : hd[u].w));
 					xo[u][k] = (unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c;
-					xv[u][k] = sfw_load(xbase + xo[u][k]);
+					xv[u][k] = PERM ? *reinterpret_cast<const double *>(xbase + xo[u][k]) : sfw_load(xbase + xo[u][k]);
 					if (sfw_pending(xv[u][k]))
 						dep[u] |= 1u << k;
 				}
@@ -135,8 +144,9 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 		}
 		r2[u].x = r2[u].y = 0.0;
 		if (ok[u]) {
+			const unsigned rsel = (PERM && UPPER) ? (unsigned)pp[u] : (unsigned)row[u];
 			r2[u] = *reinterpret_cast<const double2_t *>(
-			    rbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+			    rbase + (rsel * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
 			if (a.rscale) {
 				const double2_t s2 = *reinterpret_cast<const double2_t *>(
 				    sbase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
@@ -226,9 +236,17 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 					o1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
 				}
 				if (!done[u] && gready && slot == 0 && q < HB) {
-					char *const dst = obase + ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
+					const unsigned osel = PERM ? (unsigned)pp[u] : (unsigned)row[u];
+					char *const dst = obase + (osel * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
 					sfw_store(dst, o0);
 					sfw_store(dst + 8, o1);
+					if (PERM && UPPER && a.xnat) {
+						double2_t o2;
+						o2.x = o0;
+						o2.y = o1;
+						*reinterpret_cast<double2_t *>(reinterpret_cast<char *>(a.xnat) +
+						                               ((unsigned)row[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q)) = o2;
+					}
 				}
 				done[u] = done[u] || gready;
 			}
@@ -430,8 +448,13 @@ void set_levelw_enabled(int on)
 // One exact triangular pass over the level-ordered copy described by (ptr, cols, a.vals).  a.xout must
 // have been filled with the pending pattern.  Returns false when this kernel does not cover the case
 // (caller uses the general single-launch kernel).  The abort flag ls.ctl[1] is checked by the caller.
+bool syncfree_wide_supported(const Pattern &pat)
+{
+	return g_levelw_enabled && (pat.bs == 4 || pat.bs == 8) && !pat.rowmajor;
+}
+
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          const int4 *head, hipStream_t s)
+                          const int4 *head, hipStream_t s, bool permuted)
 {
 	const int bs = a.pat.bs;
 	if (!g_levelw_enabled || a.pat.rowmajor || ls.count == 0)
@@ -470,8 +493,12 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 	{                                                                                                      \
 		constexpr int RC = LWGeo<B>::RSTEP * U;                                                            \
 		const unsigned grid = (unsigned)(((long)ls.count + RC - 1) / RC);                                  \
-		hipLaunchKernelGGL((sfw_kernel<B, UP, U>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, ls.rows, \
-		                   ls.count, ls.ctl);                                                              \
+		if (permuted)                                                                                      \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
+			                   ls.rows, ls.count, ls.ctl);                                                 \
+		else                                                                                               \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
+			                   ls.rows, ls.count, ls.ctl);                                                 \
 	}
 	const int v = g_levelw_variant;
 	if (bs == 4) {

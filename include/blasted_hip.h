@@ -191,6 +191,7 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
  * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
  * factor's triangles (one more copy of the factor, one copy pass per factorisation) or the factor in
  * place (environment: BLASTED_HIP_COMPACT).
+ * "levelperm=0": the exact ILU solves keep natural-order vectors instead of a level-ordered iterate.
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
  * lets a wave of that kernel prefetch several row steps instead of one. */
 int blasted_hip_set_tuning(const char *spec);

@@ -23,18 +23,21 @@ CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16
          "random_bs4", "random_csr"]
 
 
-@pytest.fixture(params=["syncfree", "syncfree_general", "syncfree_inplace", "launch"], autouse=True)
+@pytest.fixture(params=["syncfree", "syncfree_natural", "syncfree_general", "syncfree_inplace", "launch"], autouse=True)
 def level_impl(request):
     """Every test runs with each implementation of an exact pass: one launch that polls its dependencies
-    -- the streaming kernel on level-ordered copies of the factor (default, bs 4/8 column-major), the
-    general kernel on those copies, the general kernel on the factor in place -- and one launch per level."""
+    -- the streaming kernel on level-ordered copies of the factor with a level-ordered iterate (default, bs
+    4/8 column-major) or with natural-order vectors, the general kernel on those copies, the general kernel
+    on the factor in place -- and one launch per level."""
     capi.set_tuning("level=" + ("launch" if request.param == "launch" else "syncfree"))
     capi.set_tuning("levelstore=" + ("0" if request.param == "syncfree_inplace" else "1"))
     capi.set_tuning("levelwide=" + ("0" if request.param == "syncfree_general" else "1"))
+    capi.set_tuning("levelperm=" + ("0" if request.param == "syncfree_natural" else "1"))
     yield request.param
     capi.set_tuning("level=syncfree")
     capi.set_tuning("levelstore=1")
     capi.set_tuning("levelwide=1")
+    capi.set_tuning("levelperm=1")
 
 
 def check_stats(p, impl):
