@@ -44,12 +44,12 @@ __device__ __forceinline__ bool sfw_pending(double v)
 	return (unsigned long long)__double_as_longlong(v) == SFW_PENDING;
 }
 
-template <int BS>
+template <int BS, int NBV>
 struct LWGeo {
 	static constexpr int HB = BS / 2;
 	static constexpr int LPB = BS * HB;
-	static constexpr int NB = 2;  // two block slots per row (one slot, as in kernels_sweepw.hip, measured slower
-	                              // here: 7.3 instead of 6.5 ms per exact apply at 256^3 -- this pass is latency-bound)
+	static constexpr int NB = NBV;  // block slots per row: the lower solve (3 blocks on a 7-point row) is faster with
+	                                // one (2.46 against 2.64 ms at 256^3), the upper solve (1 + 3) with two (2.92 / 3.03)
 	static constexpr int G = LPB * NB;
 	static constexpr int RPW = 64 / G;
 	static constexpr int RSTEP = 4 * RPW;
@@ -73,12 +73,12 @@ struct LWGeo {
 // and writes z both level-ordered (for its own gathers) and, through a.xnat, in natural order.  Gathers
 // look through the caches first: an entry is written once after the fill, so anything but "pending" is
 // final wherever it is read from; a (possibly stale) "pending" is re-read coherently.
-template <int BS, bool UPPER, int UNR, bool PERM>
+template <int BS, bool UPPER, int UNR, bool PERM, int NBV>
 __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *__restrict__ ptr,
                                                   const int *__restrict__ cols, const int4 *__restrict__ head,
                                                   const int *__restrict__ rows, const int count, int *ctl)
 {
-	using Ge = LWGeo<BS>;
+	using Ge = LWGeo<BS, NBV>;
 	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
 	constexpr int KFIX = 4 / NB;  // the four head entries
 	constexpr unsigned long long GMASK = G == 64 ? ~0ull : ((1ull << G) - 1ull);
@@ -491,13 +491,14 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 #define BHIP_LW(B, UP, U)                                                                                  \
 	{                                                                                                      \
-		constexpr int RC = LWGeo<B>::RSTEP * U;                                                            \
+		constexpr int NBV = (UP || B == 8) ? 2 : 1;                                                        \
+		constexpr int RC = LWGeo<B, NBV>::RSTEP * U;                                                       \
 		const unsigned grid = (unsigned)(((long)ls.count + RC - 1) / RC);                                  \
 		if (permuted)                                                                                      \
-			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true, NBV>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
 			                   ls.rows, ls.count, ls.ctl);                                                 \
 		else                                                                                               \
-			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false, NBV>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
 			                   ls.rows, ls.count, ls.ctl);                                                 \
 	}
 	const int v = g_levelw_variant;
