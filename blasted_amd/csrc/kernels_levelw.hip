@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 // part requested at once (their column indices come from the head); longer rows finish at commit time.
 typedef double2_t d2u_t __attribute__((aligned(8)));  // 16-byte access at 8-byte alignment
 
-template <int BS, bool UPPER>
+template <int BS, bool UPPER, bool PERM>
 __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int *__restrict__ ptr,
                                                     const int *__restrict__ cols, const int4 *__restrict__ head,
                                                     const int *__restrict__ rows, const int count, int *ctl)
@@ -327,8 +327,14 @@ __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int
 			if (!(UPPER && k == 0)) {  // item 0 of the upper copy is the diagonal block
 				const int col = k == 0 ? h0.x : (k == 1 ? h0.y : (k == 2 ? h0.z : (k == 3 ? h0.w : (k == 4 ? h1.x : (k == 5 ? h1.y : (k == 6 ? h1.z : h1.w))))));
 				xo[k] = (unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx;
-				xa[k] = sfw_load(xbase + xo[k]);
-				xb[k] = sfw_load(xbase + xo[k] + 8);
+				if (PERM) {  // level-ordered iterate: first look through the caches (see sfw_kernel)
+					const d2u_t x2 = *reinterpret_cast<const d2u_t *>(xbase + xo[k]);
+					xa[k] = x2.x;
+					xb[k] = x2.y;
+				} else {
+					xa[k] = sfw_load(xbase + xo[k]);
+					xb[k] = sfw_load(xbase + xo[k] + 8);
+				}
 				if (sfw_pending(xa[k]) || sfw_pending(xb[k]))
 					dep |= 1u << k;
 			}
@@ -336,7 +342,8 @@ __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int
 	}
 	double rv = 0.0;
 	if (ok && t < BS) {
-		rv = a.rhs[(long)row * BS + t];
+		const long rsel = (PERM && UPPER) ? (long)p : (long)row;  // the level-ordered y of the lower solve
+		rv = a.rhs[rsel * BS + t];
 		if (a.rscale)
 			rv *= a.rscale[(long)row * BS + t];
 	}
@@ -417,8 +424,11 @@ __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int
 				__builtin_amdgcn_wave_barrier();
 				out = pr;
 			}
-			if (!done && gready && t < BS)
-				sfw_store(obase + ((unsigned)row * (unsigned)ROWBYTES + 8u * (unsigned)t), out);
+			if (!done && gready && t < BS) {
+				sfw_store(obase + ((unsigned)(PERM ? p : row) * (unsigned)ROWBYTES + 8u * (unsigned)t), out);
+				if (PERM && UPPER && a.xnat)
+					a.xnat[(long)row * BS + t] = out;
+			}
 			done = done || gready;
 		}
 		if (__builtin_amdgcn_ballot_w64(!done) == 0ull)
@@ -450,7 +460,7 @@ void set_levelw_enabled(int on)
 // (caller uses the general single-launch kernel).  The abort flag ls.ctl[1] is checked by the caller.
 bool syncfree_wide_supported(const Pattern &pat)
 {
-	return g_levelw_enabled && (pat.bs == 4 || pat.bs == 8) && !pat.rowmajor;
+	return g_levelw_enabled && pat.bs >= 3 && pat.bs <= 8 && pat.bs != 6 && !pat.rowmajor;
 }
 
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
@@ -465,8 +475,12 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 	{                                                                                                           \
 		constexpr int RS = 4 * (64 / (B == 3 ? 8 : (B == 5 ? 16 : 32)));                                        \
 		const unsigned grid = (unsigned)(((long)ls.count + RS - 1) / RS);                                       \
-		hipLaunchKernelGGL((sfodd_kernel<B, UP>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, ls.rows,     \
-		                   ls.count, ls.ctl);                                                                   \
+		if (permuted)                                                                                           \
+			hipLaunchKernelGGL((sfodd_kernel<B, UP, true>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head,    \
+			                   ls.rows, ls.count, ls.ctl);                                                      \
+		else                                                                                                    \
+			hipLaunchKernelGGL((sfodd_kernel<B, UP, false>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head,   \
+			                   ls.rows, ls.count, ls.ctl);                                                      \
 	}
 		if (bs == 3) {
 			if (upper) BHIP_LO(3, true) else BHIP_LO(3, false)
