@@ -270,7 +270,7 @@ static void restore_ytemp(blasted_hip_prec p)
 // p->yperm, the upper solve reads it there, gathers from p->zperm and also writes z in natural order to x.
 // Returns 0 when this form does not apply (the caller continues with the natural-order forms).
 static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, double *x, LevelSchedule &ls,
-                               const LevelView &view)
+                               const LevelView &view, bool sgs)
 {
 	if (!g_level_perm || !syncfree_wide_supported(p->pat))
 		return 0;
@@ -285,7 +285,7 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 	a.xnat = upper ? x : nullptr;
 	if (upper)
 		a.rhs = p->yperm;
-	if (!launch_syncfree_wide(a, upper, ls, view.ptr, view.colp, view.headp, p->stream, true))
+	if (!launch_syncfree_wide(a, upper, ls, view.ptr, view.colp, view.headp, p->stream, true, sgs))
 		return 0;
 	int ctl[2] = {0, 0};
 	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, p->stream));
@@ -318,13 +318,18 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 			use_view = level_view(p, part == PART_UPPER, view, p->vals, p->mat_lvl);
 		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
 		const bool ilu_upper = part == PART_UPPER && post == POST_D_SUB && dsrc == D_VALS_DIAG;
-		if (use_view && a.vals == p->iluvals && (ilu_lower || ilu_upper)) {
-			if (ilu_lower)
+		const bool sgs_fwd = part == PART_LOWER && post == POST_D_SUB && dsrc == D_DBLOCKS;
+		const bool sgs_bwd = part == PART_UPPER && post == POST_SUB_D && dsrc == D_DBLOCKS;
+		const bool ilu_ops = a.vals == p->iluvals && (ilu_lower || ilu_upper);
+		const bool sgs_ops = a.vals == p->vals && (sgs_fwd || sgs_bwd) && (p->pat.bs == 4 || p->pat.bs == 8);
+		if (use_view && (ilu_ops || sgs_ops)) {
+			const bool up = ilu_upper || sgs_bwd;
+			if (!up)
 				p->y_in_level_order = false;
-			const int done = exact_pass_permuted(p, a, ilu_upper, x, ls, view);
+			const int done = exact_pass_permuted(p, a, up, x, ls, view, sgs_ops);
 			if (done)
 				return done;
-			if (ilu_upper)
+			if (up)
 				restore_ytemp(p);
 		}
 		launch_syncfree_fill(x, p->n(), p->stream);

@@ -148,7 +148,7 @@ bool launch_syncfree_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, 
                            hipStream_t s, const LevelView *view = nullptr);
 // kernels_levelw.hip (streaming exact triangular pass, column-major bs 4 / 8, level-ordered copies)
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          const int4 *head, hipStream_t s, bool permuted = false);
+                          const int4 *head, hipStream_t s, bool permuted = false, bool sgs = false);
 bool syncfree_wide_supported(const Pattern &pat);
 void launch_level_unpermute(const LevelSchedule &ls, int bs, const double *xperm, double *xnat, hipStream_t s);
 void set_levelw_enabled(int on);

@@ -769,8 +769,11 @@ bool launch_syncfree_sweep(const SweepArgs &a_, Part part, Post post, DSrc dsrc,
 		a.pat.bcolind = view->bcolind;
 		const bool ilu_lower = part == PART_LOWER && post == POST_SUB && dsrc == D_NONE;
 		const bool ilu_upper = part == PART_UPPER && post == POST_D_SUB && dsrc == D_VALS_DIAG;
-		if ((ilu_lower || ilu_upper) &&
-		    launch_syncfree_wide(a, ilu_upper, ls, view->ptr, view->bcolind, view->head, s))
+		const bool sgs_fwd = part == PART_LOWER && post == POST_D_SUB && dsrc == D_DBLOCKS;
+		const bool sgs_bwd = part == PART_UPPER && post == POST_SUB_D && dsrc == D_DBLOCKS;
+		if ((ilu_lower || ilu_upper || sgs_fwd || sgs_bwd) &&
+		    launch_syncfree_wide(a, ilu_upper || sgs_bwd, ls, view->ptr, view->bcolind, view->head, s, false,
+		                         sgs_fwd || sgs_bwd))
 			return true;
 	}
 	if (!ls.built)

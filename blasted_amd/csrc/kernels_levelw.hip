@@ -73,7 +73,10 @@ struct LWGeo {
 // and writes z both level-ordered (for its own gathers) and, through a.xnat, in natural order.  Gathers
 // look through the caches first: an entry is written once after the fill, so anything but "pending" is
 // final wherever it is read from; a (possibly stale) "pending" is re-read coherently.
-template <int BS, bool UPPER, int UNR, bool PERM, int NBV>
+// SGS = false: the ILU solves above.  SGS = true: the exact symmetric Gauss-Seidel passes on the copies of
+// the MATRIX with D^-1 from a.dvals (dblocks, by row): forward y_i = D_i^-1 (rhs_i - sum_lower A_ij y_j),
+// backward z_i = rhs_i - D_i^-1 sum_upper A_ij z_j (the copy's first block, A's own diagonal, is skipped).
+template <int BS, bool UPPER, int UNR, bool PERM, int NBV, bool SGS>
 __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *__restrict__ ptr,
                                                   const int *__restrict__ cols, const int4 *__restrict__ head,
                                                   const int *__restrict__ rows, const int count, int *ctl)
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 	double xv[UNR][KFIX];
 	unsigned xo[UNR][KFIX];
 	unsigned dep[UNR];
-	double2_t r2[UNR];
+	double2_t r2[UNR], dvs[UNR];
 #pragma unroll
 	for (int u = 0; u < UNR; u++) {
 		dep[u] = 0u;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 			bv[u][k].y = 0.0;
 			xv[u][k] = 0.0;
 			xo[u][k] = 0u;
-			if (jj < jend[u]) {
+			if (jj < jend[u] && !(SGS && UPPER && jj == jbeg[u])) {
 				bv[u][k] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(
 				    vbase + ((long)jj * Ge::BLKBYTES + 16 * q)));
 				if (!(UPPER && jj == jbeg[u])) {  // the diagonal block multiplies no iterate entry
@@ -142,6 +145,10 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 				}
 			}
 		}
+		dvs[u].x = dvs[u].y = 0.0;
+		if (SGS && ok[u] && slot == 0)
+			dvs[u] = *reinterpret_cast<const double2_t *>(reinterpret_cast<const char *>(a.dvals) +
+			                                              ((long)row[u] * Ge::BLKBYTES + 16 * q));
 		r2[u].x = r2[u].y = 0.0;
 		if (ok[u]) {
 			const unsigned rsel = (PERM && UPPER) ? (unsigned)pp[u] : (unsigned)row[u];
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 			const unsigned long long rb = __builtin_amdgcn_ballot_w64(dep[u] == 0u);
 			bool gready = ((rb >> gbase) & GMASK) == GMASK;
 			if (__builtin_amdgcn_ballot_w64(gready && !done[u]) != 0ull) {
-				double acc0 = 0.0, acc1 = 0.0, d0 = 0.0, d1 = 0.0;
+				double acc0 = 0.0, acc1 = 0.0, d0 = SGS ? dvs[u].x : 0.0, d1 = SGS ? dvs[u].y : 0.0;
 #pragma unroll
 				for (int k = 0; k < KFIX; k++) {
-					if (UPPER && k == 0) {
+					if (!SGS && UPPER && k == 0) {
 						const bool isd = (slot == 0);  // item 0 of the row: its inverted diagonal block
 						d0 = isd ? bv[u][0].x : 0.0;
 						d1 = isd ? bv[u][0].y : 0.0;
@@ -215,11 +222,12 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 				acc0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc0);
 				acc1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc1);
 				double o0, o1;
-				if (!UPPER) {
+				if (!UPPER && !SGS) {
 					o0 = r2[u].x - acc0;
 					o1 = r2[u].y - acc1;
 				} else {
-					const double w0 = r2[u].x - acc0, w1 = r2[u].y - acc1;
+					// the vector the diagonal block multiplies: rhs - sum (ILU upper, SGS forward), sum (SGS backward)
+					const double w0 = (SGS && UPPER) ? acc0 : r2[u].x - acc0, w1 = (SGS && UPPER) ? acc1 : r2[u].y - acc1;
 					double wc;
 					if (BS == 4) {
 						const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
@@ -234,6 +242,10 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 					}
 					o0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
 					o1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
+					if (SGS && UPPER) {
+						o0 = r2[u].x - o0;
+						o1 = r2[u].y - o1;
+					}
 				}
 				if (!done[u] && gready && slot == 0 && q < HB) {
 					const unsigned osel = PERM ? (unsigned)pp[u] : (unsigned)row[u];
@@ -464,11 +476,13 @@ bool syncfree_wide_supported(const Pattern &pat)
 }
 
 bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &ls, const int *ptr, const int *cols,
-                          const int4 *head, hipStream_t s, bool permuted)
+                          const int4 *head, hipStream_t s, bool permuted, bool sgs)
 {
 	const int bs = a.pat.bs;
 	if (!g_levelw_enabled || a.pat.rowmajor || ls.count == 0)
 		return false;
+	if (sgs && bs != 4 && bs != 8)
+		return false;  // the Gauss-Seidel passes exist in the bs 4 / 8 kernel only
 	if (bs == 3 || bs == 5 || bs == 7) {
 		BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 #define BHIP_LO(B, UP)                                                                                          \
@@ -496,7 +510,8 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 	if (bs != 4 && bs != 8)
 		return false;
 	auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
-	if (misaligned(a.vals) || misaligned(a.rhs) || misaligned(a.rscale) || misaligned(a.xout))
+	if (misaligned(a.vals) || misaligned(a.rhs) || misaligned(a.rscale) || misaligned(a.xout) ||
+	    (sgs && misaligned(a.dvals)))
 		return false;
 	// A workgroup is ONE row step (16 rows at bs=4, 4 at bs=8), all of it requested at once: rows of a level
 	// are independent, so nothing may be serialised behind another row's wait -- with 128-row chunks the
@@ -508,12 +523,18 @@ bool launch_syncfree_wide(const SweepArgs &a, bool upper, const LevelSchedule &l
 		constexpr int NBV = (UP || B == 8) ? 2 : 1;                                                        \
 		constexpr int RC = LWGeo<B, NBV>::RSTEP * U;                                                       \
 		const unsigned grid = (unsigned)(((long)ls.count + RC - 1) / RC);                                  \
-		if (permuted)                                                                                      \
-			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true, NBV>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
-			                   ls.rows, ls.count, ls.ctl);                                                 \
+		if (sgs && permuted)                                                                               \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true, NBV, true>), dim3(grid), dim3(256), 0, s, a, ptr, cols, \
+			                   head, ls.rows, ls.count, ls.ctl);                                           \
+		else if (sgs)                                                                                      \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false, NBV, true>), dim3(grid), dim3(256), 0, s, a, ptr, cols, \
+			                   head, ls.rows, ls.count, ls.ctl);                                           \
+		else if (permuted)                                                                                 \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, true, NBV, false>), dim3(grid), dim3(256), 0, s, a, ptr, cols, \
+			                   head, ls.rows, ls.count, ls.ctl);                                           \
 		else                                                                                               \
-			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false, NBV>), dim3(grid), dim3(256), 0, s, a, ptr, cols, head, \
-			                   ls.rows, ls.count, ls.ctl);                                                 \
+			hipLaunchKernelGGL((sfw_kernel<B, UP, U, false, NBV, false>), dim3(grid), dim3(256), 0, s, a, ptr, cols, \
+			                   head, ls.rows, ls.count, ls.ctl);                                           \
 	}
 	const int v = g_levelw_variant;
 	if (bs == 4) {
