@@ -11,7 +11,7 @@ sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from blasted_amd import capi, workloads as W  # noqa: E402
 
 
-def bicgstab(A, M, b, tol=1e-8, maxit=2000):
+def bicgstab(A, M, b, tol=1e-8, maxit=1200):
     x = torch.zeros_like(b)
     r = b.clone()
     rhat = r.clone()
@@ -40,8 +40,8 @@ def bicgstab(A, M, b, tol=1e-8, maxit=2000):
         res = float(r.norm()) / bn
         if res < tol:
             return x, it, res
-        if not (res == res):
-            return x, it, res
+        if not (res == res) or res > 1e6:
+            return x, it, res  # diverged
     return x, maxit, float(r.norm()) / bn
 
 
