@@ -221,3 +221,61 @@ def test_no_dependence_inside_a_level(golden, case):
     offp = rowofp != mp["bcolind"]
     assert not np.any(lvl_of[rowofp[offp]] == lvl_of[mp["bcolind"][offp]])
     p.close()
+
+
+def arrowhead(nb, bs, rowmajor=False):
+    """Block arrowhead + tridiagonal pattern: row 0 is coupled to every row (a row far longer than the
+    register-held block passes of the single-launch kernels), row i to i-1 and i+1 (nb levels)."""
+    rows, cols = [], []
+    for i in range(nb):
+        cs = {i, 0}
+        if i > 0:
+            cs.add(i - 1)
+        if i + 1 < nb:
+            cs.add(i + 1)
+        if i == 0:
+            cs = set(range(nb))
+        for c in sorted(cs):
+            rows.append(i)
+            cols.append(c)
+    rows, cols = np.array(rows), np.array(cols)
+    rp = np.zeros(nb + 1, dtype=np.int64)
+    np.add.at(rp, rows + 1, 1)
+    rp = np.cumsum(rp)
+    rng = np.random.default_rng(5)
+    vals = rng.uniform(-1.0, 1.0, (rows.size, bs, bs)) * (0.2 / bs)
+    vals[rows == 0] *= 4.0 / nb
+    vals[cols == 0] *= 4.0 / nb
+    dg = np.nonzero(rows == cols)[0]
+    vals[dg] = np.eye(bs)[None] * 2.0 + rng.uniform(-0.1, 0.1, (nb, bs, bs))
+    if rowmajor:
+        vals = vals.transpose(0, 2, 1)
+    return {"nbrows": nb, "nnzb": int(rows.size), "bs": bs, "rowmajor": bool(rowmajor),
+            "browptr": rp.astype(np.int32), "bcolind": cols.astype(np.int32), "diagind": dg.astype(np.int32),
+            "vals": np.ascontiguousarray(vals.reshape(-1))}
+
+
+@pytest.mark.parametrize("bs,rowmajor", [(4, False), (5, False), (8, False), (1, False), (4, True)])
+def test_exact_passes_with_a_very_long_row(bs, rowmajor, level_impl):
+    """Rows longer than what the single-launch kernels hold in registers: their remainder loops (and, for
+    the general kernel, the fallback to one launch per level) give the serial result all the same."""
+    m = arrowhead(300, bs, rowmajor)
+    n = m["nbrows"] * bs
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    assert p.level_count() == 300
+    p.ilu0_factorize(-1)
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(p.get_iluvals(), f) < 1e-11
+    assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)) < 1e-11
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    assert rel(p.sgs_apply(r, 1, mode=capi.LEVEL), O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL)) < 1e-11
+    x = p.sgs_relax(r, np.zeros(n), 2, mode=capi.LEVEL)
+    assert rel(x, O.sgs_relax(m, gd, r, maxits=2, mode=O.GS_SERIAL)) < 1e-11
+    # and the asynchronous kernels' remainder loops
+    z = p.ilu0_apply(r, 310, mode=capi.ASYNC)
+    assert rel(z, O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)) < 1e-10
+    assert rel(p.spmv(r), O.spmv(m, r)) < 1e-13
+    assert p.level_stats()["syncfree_aborts"] == 0
+    p.close()
