@@ -251,7 +251,10 @@ def main():
             try:
                 ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
                 st = p.level_stats()
+                exf = _t(lambda: p.ilu0_factorize(-1), reps=2)
+                asf = _t(lambda: p.ilu0_factorize(args.build_sweeps), reps=2)
                 out["exact_apply"] = {"ms": ex, "levels": st["levels"], "syncfree_aborts": st["syncfree_aborts"],
+                                      "exact_factor_ms": exf, "async_factor_ms": asf,
                                       "note": "one exact L and U solve (mode LEVEL), beside ms_per_step for %d+%d "
                                               "asynchronous sweeps" % (s, s)}
             except Exception as e:
