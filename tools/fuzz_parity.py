@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Randomised differential test: many small random BSR matrices (size, block size, layout, density, with or
+without scaling) through every operator and mode of the C ABI against the CPU oracle.
+usage: fuzz_parity.py [cases=150] [seed=1]"""
+import sys
+import time
+
+import numpy as np
+
+ROOT = __file__.rsplit("/tools/", 1)[0]
+sys.path.insert(0, ROOT)
+import oracle as O  # noqa: E402
+from blasted_amd import capi, workloads as W  # noqa: E402
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    O.set_num_threads(8)
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    worst = {}
+
+    def check(name, got, want, tol):
+        e = rel(got, want)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert e < tol, (name, e, case)
+
+    for it in range(ncases):
+        bs = int(rng.choice([1, 2, 3, 4, 5, 7, 8]))
+        nb = int(rng.integers(1, 700)) if rng.integers(0, 12) else int(rng.integers(5000, 60000))
+        rm = bool(rng.integers(0, 2)) and bs > 1
+        dens = int(rng.integers(1, 12))
+        sc = bool(rng.integers(0, 2))
+        # a random kernel-variant selection, so that every implementation of a pass meets every shape
+        tune = {k: int(rng.integers(0, 2)) for k in ("levelstore", "levelwide", "levelperm", "compact",
+                                                     "interleave", "sweepodd", "sweepwr", "factorodd",
+                                                     "factor4", "factor8", "gunroll")}
+        tune["level"] = str(rng.choice(["syncfree", "syncfree", "launch"]))
+        for k, v in tune.items():
+            capi.set_tuning("%s=%s" % (k, v))
+        tune["sweepw"] = str(rng.choice(["generic", "r128,nt1,u2,s1", "r128,nt0,u2,s2", "r128,nt1,u1,s3",
+                                         "r256,nt1,u2,s1", "r256,nt0,u1,s2"]))
+        capi.set_tuning(tune["sweepw"])
+        case = dict(it=it, bs=bs, nb=nb, rowmajor=rm, avg_offdiag=dens, scaling=sc, tune=tune)
+        m = W.random_bsr(nb, bs, avg_offdiag=dens, seed=int(rng.integers(1, 1 << 30)), rowmajor=rm)
+        n = nb * bs
+        r = rng.uniform(-1, 1, n)
+        x0 = rng.uniform(-1, 1, n)
+        p = capi.Prec(0)
+        p.set_matrix(m)
+        # integer structures
+        pos = O.ilu_positions(m)
+        # SpMV
+        check("spmv", p.spmv(r), O.spmv(m, r), 1e-12)
+        check("gemv3", p.gemv3(0.7, r, -1.3, x0), O.gemv3(m, 0.7, r, -1.3, x0), 1e-12)
+        # factorisation: synchronous sweeps and the exact form
+        init = int(rng.choice([capi.INIT_F_ORIGINAL, capi.INIT_F_SGS]))
+        p.ilu0_factorize(2, init=init, usescale=sc, mode=capi.JACOBI_SYNC)
+        want = O.ilu0_factorize(m, pos, 2, mode=O.JACOBI_SYNC, init=init, usescale=sc)
+        if np.all(np.isfinite(want["iluvals"])) and np.abs(want["iluvals"]).max() < 1e8:
+            check("factor_sync", p.get_iluvals(), want["iluvals"], 1e-10)
+        p.ilu0_factorize(-1, usescale=sc)
+        fe = O.ilu0_factorize(m, pos, 1, mode=O.GS_SERIAL, usescale=sc)
+        if not (np.all(np.isfinite(fe["iluvals"])) and np.abs(fe["iluvals"]).max() < 1e8):
+            p.close()
+            continue
+        check("factor_exact", p.get_iluvals(), fe["iluvals"], 1e-9)
+        f = p.get_iluvals()
+        scale = p.get_scale() if sc else None
+        # apply: synchronous, exact, asynchronous to convergence
+        ainit = int(rng.choice([capi.INIT_A_ZERO, capi.INIT_A_JACOBI]))
+        check("apply_sync", p.ilu0_apply(r, 3, init=ainit, mode=capi.JACOBI_SYNC),
+              O.ilu0_apply(m, f, r, 3, mode=O.JACOBI_SYNC, init=ainit, scale=scale), 1e-10)
+        ze = O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL, scale=scale)
+        if np.all(np.isfinite(ze)) and np.abs(ze).max() < 1e8:
+            check("apply_exact", p.ilu0_apply(r, 1, mode=capi.LEVEL), ze, 1e-9)
+            check("apply_async", p.ilu0_apply(r, p.level_count() + 2, mode=capi.ASYNC), ze, 1e-8)
+        # Jacobi / SGS / relaxations
+        p.jacobi_compute()
+        d = p.get_dblocks()
+        check("jacobi", p.jacobi_apply(r), O.jacobi_apply(m, d, r), 1e-12)
+        check("sgs_sync", p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC), O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC), 1e-10)
+        check("sgs_exact", p.sgs_apply(r, 1, mode=capi.LEVEL), O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL), 1e-9)
+        xr = O.sgs_relax(m, d, r, x0=x0, maxits=2, mode=O.GS_SERIAL)
+        if np.all(np.isfinite(xr)) and np.abs(xr).max() < 1e8:
+            check("relax_exact", p.sgs_relax(r, x0.copy(), 2, mode=capi.LEVEL), xr, 1e-9)
+            check("relax_sync", p.sgs_relax(r, x0.copy(), 2, mode=capi.JACOBI_SYNC),
+                  O.sgs_relax(m, d, r, x0=x0, maxits=2, mode=O.JACOBI_SYNC), 1e-10)
+            check("gs_exact", p.gs_relax(r, x0.copy(), 2, mode=capi.LEVEL),
+                  O.gs_relax(m, d, r, x0=x0, nsweeps=2, mode=O.GS_SERIAL), 1e-9)
+            xj = x0.copy()
+            p.jacobi_relax(r, xj, 2)
+            check("jacobi_relax", xj, O.jacobi_relax(m, d, r, x0=x0, maxits=2)[0], 1e-10)
+        assert p.level_stats()["syncfree_aborts"] == 0, case
+        p.close()
+    for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
+                 "sweepodd=1", "sweepwr=1", "factorodd=1", "factor4=1", "factor8=1", "gunroll=0",
+                 "r128,nt1,u2,s1"):
+        capi.set_tuning(spec)
+    print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
+    for k in sorted(worst):
+        print("  %-14s %.2e" % (k, worst[k]))
+    print("fuzz ok")
+
+
+if __name__ == "__main__":
+    main()
