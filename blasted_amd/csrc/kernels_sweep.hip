@@ -32,6 +32,7 @@
 // (kernels_ilu0_factorize.hpp:34-40).
 #include "ctx.hpp"
 #include "lanes.hpp"
+#include "stage.hpp"
 #include "sweep_geo.hpp"
 
 namespace bhip {
@@ -66,30 +67,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;  // rows [r0, r0 + rc)
 
-	for (int k = tid; k <= rc; k += 256)
-		s_rp[k] = a.pat.browptr[r0 + k];
-	for (int k = tid; k < rc; k += 256)
-		s_dg[k] = a.pat.diagind[r0 + k];
-	__syncthreads();
 	int jlo, jhi;
-	if (PART == PART_LOWER) {
-		jlo = s_rp[0];
-		jhi = s_dg[rc - 1];
-	} else if (PART == PART_UPPER) {
-		jlo = s_dg[0];
-		jhi = s_rp[rc];
-	} else {
-		jlo = s_rp[0];
-		jhi = s_rp[rc];
-	}
-	jlo = __builtin_amdgcn_readfirstlane(jlo);
-	jhi = __builtin_amdgcn_readfirstlane(jhi);
-	if (PART != PART_NONE) {
-		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
-		for (int k = tid; k < ncol; k += 256)
-			s_col[k] = a.pat.bcolind[jlo + k];
-	}
-	__syncthreads();
+	stage_chunk_indices<PART, RCHUNK, CAP>(a.pat, r0, rc, tid, s_rp, s_dg, s_col, jlo, jhi);
 
 	// wave-uniform 64-bit bases + 32-bit per-lane byte offsets (limits checked by sweep_offsets_fit)
 	const char *const vbase = reinterpret_cast<const char *>(a.vals + (long)jlo * BS2);

@@ -22,9 +22,14 @@
 //  * XCD-aware chunk numbering: each XCD sweeps one contiguous range of rows.
 #include "ctx.hpp"
 #include "lanes.hpp"
+#include "stage.hpp"
 
 #include <cstdlib>
 #include <cstring>
+
+#ifndef BHIP_DIAG
+#define BHIP_DIAG 0  // tools/probes/build_diag.sh: timing-only variants (wrong results) that drop one cost at a time
+#endif
 
 namespace bhip {
 
@@ -36,6 +41,17 @@ __device__ __forceinline__ double2_t load_block16(const double *p)
 	if (NT)
 		return __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(p));
 	return *reinterpret_cast<const double2_t *>(p);
+}
+
+// v of lane w of the caller's quad, in every lane of the quad (w is a compile-time constant after unrolling)
+__device__ __forceinline__ double quad_bcast(const double v, const int w)
+{
+	switch (w) {
+	case 0: return dpp_mov<0x00>(v);
+	case 1: return dpp_mov<0x55>(v);
+	case 2: return dpp_mov<0xAA>(v);
+	default: return dpp_mov<0xFF>(v);
+	}
 }
 
 template <int BS, int NBV>
@@ -76,33 +92,31 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	// rows of this chunk in index order: [r0, r0 + rc)
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
-	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;
+	const int descending = (BHIP_DIAG >= 4) ? (BHIP_DIAG == 5) : a.descending;  // 4: ascending, 5: descending whatever the sweep
+	const int r0 = descending ? (int)(nb - lin0 - rc) : (int)lin0;
 
-	for (int k = tid; k <= rc; k += 256)
-		s_rp[k] = a.pat.browptr[r0 + k];
-	for (int k = tid; k < rc; k += 256)
-		s_dg[k] = a.pat.diagind[r0 + k];
-	__syncthreads();
-	// column indices the chunk needs
 	int jlo, jhi;
-	if (PART == PART_LOWER) {
-		jlo = s_rp[0];
-		jhi = s_dg[rc - 1];
-	} else if (PART == PART_UPPER) {
-		jlo = s_dg[0];
-		jhi = s_rp[rc];
-	} else {
-		jlo = s_rp[0];
-		jhi = s_rp[rc];
+#if BHIP_DIAG >= 3
+	{
+		const int per = (PART == PART_LOWER) ? 3 : 4;
+		const int total = a.pat.browptr[nb];
+		for (int k = tid; k <= rc; k += 256) {
+			int v = (r0 + k) * per;
+			v = v < total - per ? v : total - per;
+			s_rp[k] = v;
+			if (k < rc)
+				s_dg[k] = (PART == PART_LOWER) ? v + per : v;
+		}
+		jlo = r0 * per;
+		jlo = jlo < total - per ? jlo : total - per;
+		jhi = jlo;
+		__syncthreads();
 	}
-	jlo = __builtin_amdgcn_readfirstlane(jlo);  // wave-uniform by construction: let the compiler know
-	jhi = __builtin_amdgcn_readfirstlane(jhi);
-	if (PART != PART_NONE) {
-		const int ncol = (jhi - jlo) < CAP ? (jhi - jlo) : CAP;
-		for (int k = tid; k < ncol; k += 256)
-			s_col[k] = a.pat.bcolind[jlo + k];
-	}
-	__syncthreads();
+#elif BHIP_DIAG == 2
+	stage_chunk_indices<PART, RCHUNK, 0>(a.pat, r0, rc, tid, s_rp, s_dg, s_col, jlo, jhi);
+#else
+	stage_chunk_indices<PART, RCHUNK, CAP>(a.pat, r0, rc, tid, s_rp, s_dg, s_col, jlo, jhi);
+#endif
 
 	// Chunk-relative addressing: wave-uniform 64-bit bases (SGPRs) + 32-bit per-lane byte offsets.  The
 	// host checks that a chunk's blocks and the whole vector stay below 4 GiB (launch_sweepw).
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			const int slotpos = wave * RPW + g;
 			const int ls = a.interleave ? slotpos * NSTEPS + (step0 + u) : (step0 + u) * RSTEP + slotpos;
 			ok[u] = ls < rc;
-			const int lr = ok[u] ? (a.descending ? rc - 1 - ls : ls) : 0;
+			const int lr = ok[u] ? (descending ? rc - 1 - ls : ls) : 0;
 			lrow[u] = lr;
 			const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1];
 			dgp[u] = s_dg[lr];
@@ -151,6 +165,32 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 		double2_t bv[UNR][KFIX];
 		double xv[UNR][KFIX];
 		double2_t dv[UNR], r2[UNR], s2[UNR];
+		// bs=4, one slot per row: the x segments of four passes (4 x 32 bytes) are fetched by ONE 16-byte
+		// load per lane -- lane w of quad Q takes half Q of the segment of pass 4*kg + w -- and handed out
+		// by quad broadcasts in the arithmetic below, instead of one 8-byte gather per pass (same-process
+		// A/B at 256^3: lower sweep 1.517 -> 1.487 ms, upper sweep unchanged)
+		constexpr bool XG = (BS == 4 && NB == 1 && BHIP_DIAG == 0);
+		constexpr int NXG = XG ? KFIX / 4 : 1;
+		double2_t xg[UNR][NXG];
+		constexpr bool xg_on = XG;
+		if (xg_on) {
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+#pragma unroll
+				for (int kg = 0; kg < NXG; kg++) {
+					const int jj = jbeg[u] + 4 * kg + (q & 3);
+					xg[u][kg].x = 0.0;
+					xg[u][kg].y = 0.0;
+					const bool skip = (jj == dgp[u]) && ((PART == PART_UPPER && DSRC == D_VALS_DIAG) || PART == PART_OFFDIAG);
+					if (PART != PART_NONE && jj < jend[u] && !skip) {
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						xg[u][kg] = *reinterpret_cast<const double2_t *>(
+						    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q >> 2)));
+					}
+				}
+			}
+		}
 #pragma unroll
 		for (int u = 0; u < UNR; u++) {
 #pragma unroll
@@ -164,12 +204,19 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 					bv[u][k] = load_block16<NT>(reinterpret_cast<const double *>(
 					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
 					const bool isdiag = (jj == dgp[u]);
-					if (!((PART == PART_UPPER && DSRC == D_VALS_DIAG && isdiag) ||
-					      (PART == PART_OFFDIAG && isdiag))) {
+					if (!xg_on && !((PART == PART_UPPER && DSRC == D_VALS_DIAG && isdiag) ||
+					             (PART == PART_OFFDIAG && isdiag))) {
+#if BHIP_DIAG == 1 || BHIP_DIAG >= 3
+						xv[u][k] = 1.0;
+#elif BHIP_DIAG == 2
+						xv[u][k] = *reinterpret_cast<const double *>(
+						    xbase + ((unsigned)(r0 + lrow[u]) * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+#else
 						const int cidx = jj - jlo;
 						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
 						xv[u][k] = *reinterpret_cast<const double *>(
 						    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+#endif
 					}
 				}
 			}
@@ -194,6 +241,14 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			double d0 = dv[u].x, d1 = dv[u].y;  // entries (2q, 2q+1) of D, in block slot 0
 			double acc0 = 0.0, acc1 = 0.0;
 			if (PART != PART_NONE) {
+				if (xg_on) {
+#pragma unroll
+					for (int k = 0; k < KFIX; k++) {
+						// component c of the segment of pass k: held by lane k%4 of this lane's quad (c/2 = quad)
+						const double gx = quad_bcast(xg[u][k / 4].x, k & 3), gy = quad_bcast(xg[u][k / 4].y, k & 3);
+						xv[u][k] = (c & 1) ? gy : gx;
+					}
+				}
 #pragma unroll
 				for (int k = 0; k < KFIX; k++) {
 					if (PART == PART_UPPER && DSRC == D_VALS_DIAG && k == 0) {

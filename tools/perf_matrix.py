@@ -16,7 +16,10 @@ def main():
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--bs", type=int, nargs="+", default=[1, 2, 3, 4, 5, 7, 8])
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--lib", default=None, help="another build of libblasted_hip.so (A/B of two commits)")
     a = ap.parse_args()
+    if a.lib:
+        capi.LIBPATH = os.path.abspath(a.lib)
     dev = torch.device("cuda", 0)
     for bs in a.bs:
         n = a.n
