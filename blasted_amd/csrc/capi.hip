@@ -16,11 +16,20 @@ void set_error(const std::string &msg)
 	g_last_error = msg;
 }
 
+// BLASTED_HIP_TRACE_ALLOC=1: print every device allocation of 64 MiB and more (placement studies)
+void trace_alloc(const void *p, size_t bytes)
+{
+	static const bool on = std::getenv("BLASTED_HIP_TRACE_ALLOC") != nullptr;
+	if (on && bytes >= (64u << 20))
+		std::fprintf(stderr, "[blasted_hip] alloc %12zu B at %p\n", bytes, p);
+}
+
 template <typename T>
 static T *dev_alloc(size_t count)
 {
 	T *p = nullptr;
 	BHIP_CHECK(hipMalloc(&p, sizeof(T) * (count ? count : 1)));
+	trace_alloc(p, sizeof(T) * count);
 	return p;
 }
 

@@ -196,6 +196,8 @@ struct Timing {
 	double launches[3] = {0, 0, 0};
 };
 
+void trace_alloc(const void *p, size_t bytes);  // capi.hip
+
 }  // namespace bhip
 
 struct blasted_hip_prec_s {

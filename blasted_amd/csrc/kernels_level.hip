@@ -597,6 +597,7 @@ T *lvl_alloc(size_t count)
 {
 	void *q = nullptr;
 	BHIP_CHECK(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+	trace_alloc(q, sizeof(T) * count);
 	return static_cast<T *>(q);
 }
 

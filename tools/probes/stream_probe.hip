@@ -77,8 +77,36 @@ static double time_ms(F f, int reps = 10)
 	return ms / reps;
 }
 
-int main()
+// "rounds" mode: is a buffer's streaming rate a property of where it was allocated?
+static int rounds_mode()
 {
+	const long bytes = 8564768768L;  // the diagonal+upper copy of the 256^3 bs=4 factor
+	const long n16 = bytes / 16;
+	double *sink;
+	CK(hipMalloc(&sink, 8));
+	const size_t spacers[] = {0, 0, 1u << 20, 3u << 20, 64u << 20, 1100u << 20, 0, 7u << 20, 300u << 20, 0};
+	for (size_t sp : spacers) {
+		void *spacer = nullptr;
+		if (sp)
+			CK(hipMalloc(&spacer, sp));
+		v2d *in;
+		CK(hipMalloc(&in, bytes));
+		CK(hipMemset(in, 0, bytes));
+		const int per_wg = 4096;
+		const unsigned grid = (unsigned)((n16 + per_wg - 1) / per_wg);
+		const double t = time_ms([&] { hipLaunchKernelGGL((read_chunk_kernel<true>), dim3(grid), dim3(256), 0, 0, in, sink, n16, per_wg); }, 20);
+		std::printf("spacer %10zu B, buffer at %p: %6.3f ms  %.2f TB/s\n", sp, (void *)in, t, bytes / t / 1e9);
+		CK(hipFree(in));
+		if (spacer)
+			CK(hipFree(spacer));
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc > 1)
+		return rounds_mode();
 	const long bytes = 15032385536L;  // the 256^3 bs=4 factor
 	const long n16 = bytes / 16;
 	v2d *in, *out;
