@@ -205,6 +205,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = job_throughput(world, units_per_step, args.steps, elapsed)
         copy_gbps = measured_copy_gbps(dev)
+        # practical read ceiling of this device: the matrix's own value array through a read-only kernel
+        read_gbps = capi.measure_read_stream(m["vals"], reps=10)
         kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic = None
@@ -227,6 +229,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                         "measured_read_stream_gbps": read_gbps, "frac_of_read_stream": achieved / read_gbps,
                          "kernel": "%s (%s pass; bhip::sweepw_kernel<%d, ...> in the rocprofv3 summaries)" % (
                              {"ilu_apply": "upper triangular sweep z <- D^-1 (y - U z)",
                               "sgs_apply": "backward Gauss-Seidel sweep z <- y - D^-1 U z",

@@ -25,7 +25,8 @@ SYMBOLS = [
     "blasted_hip_gemv3", "blasted_hip_get_iluvals", "blasted_hip_get_dblocks", "blasted_hip_get_scale",
     "blasted_hip_get_ytemp", "blasted_hip_iluvals_device", "blasted_hip_set_timing",
     "blasted_hip_get_timing", "blasted_hip_buffer_alloc", "blasted_hip_buffer_free",
-    "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_set_tuning",
+    "blasted_hip_buffer_upload", "blasted_hip_buffer_download", "blasted_hip_measure_read_stream",
+    "blasted_hip_set_tuning",
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
     "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
 ]
@@ -107,6 +108,15 @@ def _loc(a):
     if hasattr(a, "is_cuda"):
         return DEVICE if a.is_cuda else HOST
     raise TypeError("expected a numpy array or a torch tensor")
+
+
+def measure_read_stream(tensor, reps=10):
+    """GB/s of a read-only stream over a CUDA tensor's storage (the practical HBM ceiling of this device)."""
+    out = C.c_double(0.0)
+    nbytes = tensor.numel() * tensor.element_size()
+    _check(lib().blasted_hip_measure_read_stream(C.c_void_p(tensor.data_ptr()), C.c_ulong(nbytes), int(reps),
+                                                 C.byref(out)))
+    return out.value
 
 
 def set_tuning(spec):

@@ -1300,6 +1300,31 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 	});
 }
 
+int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, int reps, double *gbps)
+{
+	return guarded([&] {
+		if (!dev_ptr || !gbps || reps < 1 || (reinterpret_cast<uintptr_t>(dev_ptr) & 15u))
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "measure_read_stream: 16-byte aligned device buffer, reps >= 1");
+		double *sink = dev_alloc<double>(1);
+		hipEvent_t e0, e1;
+		BHIP_CHECK(hipEventCreate(&e0));
+		BHIP_CHECK(hipEventCreate(&e1));
+		for (int r = 0; r < 2; r++)
+			launch_read_stream(dev_ptr, nbytes, sink, nullptr);
+		BHIP_CHECK(hipEventRecord(e0, nullptr));
+		for (int r = 0; r < reps; r++)
+			launch_read_stream(dev_ptr, nbytes, sink, nullptr);
+		BHIP_CHECK(hipEventRecord(e1, nullptr));
+		BHIP_CHECK(hipEventSynchronize(e1));
+		float ms = 0.f;
+		BHIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+		BHIP_CHECK(hipEventDestroy(e0));
+		BHIP_CHECK(hipEventDestroy(e1));
+		dev_free(sink);
+		*gbps = ms > 0.f ? (double)(nbytes / 16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+	});
+}
+
 /* ---- tuning -------------------------------------------------------------------------------- */
 
 int blasted_hip_set_tuning(const char *spec)

@@ -180,6 +180,7 @@ void run_diag_dominance(const Pattern &pat, const double *fvals, double *dev_scr
 // kernels_aux.hip
 long run_ilu_positions(const Pattern &pat, int **posptr, int **lowerp, int **upperp, hipStream_t s);
 void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s);
+void launch_read_stream(const void *buf, unsigned long nbytes, double *sink, hipStream_t s);
 double run_diff_norm(const double *x, const double *y, long n, double *dev_scratch, hipStream_t s);
 int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len);
 

@@ -221,4 +221,33 @@ int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len)
 	return h[0];
 }
 
+// Read-only stream over a buffer in the shape of the sweeps' value stream: a workgroup takes 64 KiB
+// contiguous, 16 bytes per lane, non-temporal (blasted_hip_measure_read_stream).
+__global__ __launch_bounds__(256) void read_stream_kernel(const double *__restrict__ in, double *__restrict__ sink,
+                                                         const long n16)
+{
+	typedef double v2d __attribute__((ext_vector_type(2)));
+	const long base = (long)blockIdx.x * 4096;
+	double acc = 0.0;
+#pragma unroll 4
+	for (int k = threadIdx.x; k < 4096; k += 256) {
+		const long i = base + k;
+		if (i < n16) {
+			const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(in) + i);
+			acc += v.x + v.y;
+		}
+	}
+	if (acc == 1.2345e300)  // never: keeps the loads alive
+		sink[0] = acc;
+}
+
+void launch_read_stream(const void *buf, unsigned long nbytes, double *sink, hipStream_t s)
+{
+	const long n16 = (long)(nbytes / 16);
+	if (n16 == 0)
+		return;
+	const unsigned grid = (unsigned)((n16 + 4095) / 4096);
+	hipLaunchKernelGGL(read_stream_kernel, dim3(grid), dim3(256), 0, s, static_cast<const double *>(buf), sink, n16);
+}
+
 }  // namespace bhip

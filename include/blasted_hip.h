@@ -173,6 +173,11 @@ int blasted_hip_buffer_alloc(void **dev_ptr, unsigned long nbytes, int device);
 int blasted_hip_buffer_free(void *dev_ptr);
 int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long nbytes);
 int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
+/* Measurement aid (bench.py's roofline object): the rate in GB/s at which this device streams nbytes of an
+ * existing device buffer through a read-only kernel shaped like the sweeps' value stream (64 KiB per
+ * workgroup, 16-byte non-temporal loads) -- the practical ceiling a sweep's algorithmic rate is read
+ * against.  Average of `reps` launches after two untimed ones, on the null stream. */
+int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, int reps, double *gbps);
 
 /* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
  * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>[,s<1|2|3>]" for the tuned bs=4/8 kernel (s: block
