@@ -23,6 +23,7 @@
 // Every entry of the factor is produced in registers and stored once per sweep.
 #include "ctx.hpp"
 #include "lanes.hpp"
+#include "stage.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -86,25 +87,9 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 	const int r0 = (int)chunk * F4_RCHUNK;
 	const int rc = (nb - r0) < F4_RCHUNK ? (nb - r0) : F4_RCHUNK;
 
-	for (int q = tid; q <= rc; q += 256)
-		s_rp[q] = a.pat.browptr[r0 + q];
-	__syncthreads();
-	const int jlo = __builtin_amdgcn_readfirstlane(s_rp[0]);
-	const int jhi = __builtin_amdgcn_readfirstlane(s_rp[rc]);
-	const int nblk = (jhi - jlo) < F4_CAPB ? (jhi - jlo) : F4_CAPB;
-	for (int q = tid; q < nblk; q += 256)
-		s_col[q] = a.pat.bcolind[jlo + q];
-	for (int q = tid; q <= nblk; q += 256)
-		s_pp[q] = a.posptr[jlo + q];
-	__syncthreads();
-	const int plo = __builtin_amdgcn_readfirstlane(s_pp[0]);
-	const int phi = __builtin_amdgcn_readfirstlane(s_pp[nblk]);
-	const int npair = (phi - plo) < F4_CAPP ? (phi - plo) : F4_CAPP;
-	for (int q = tid; q < npair; q += 256) {
-		s_lp[q] = a.lowerp[plo + q];
-		s_up[q] = a.upperp[plo + q];
-	}
-	__syncthreads();
+	int jlo, plo;
+	stage_factor_indices<F4_RCHUNK, F4_CAPB, F4_CAPP>(a.pat, a.posptr, a.lowerp, a.upperp, r0, rc, tid, s_rp, s_col,
+	                                                   s_pp, s_lp, s_up, jlo, plo);
 
 	for (int step = 0; step < F4_RCHUNK / 16; step++) {
 		const int ls = step * 16 + wave * 4 + b;  // this block slot's row inside the chunk
