@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 	const int e = RM ? r * BS + c : c * BS + r;
 	const int gbase = lane & ~(SUB - 1);
 
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const long rowlin = (long)chunk * Ge::RPB + wave * Ge::RPW + g;
 	const bool rowok = rowlin < (a.rows ? a.nrows : a.pat.nbrows);
 	const int irow = rowok ? (a.rows ? a.rows[rowlin] : (int)rowlin) : 0;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 	const int offD = m * 4 + k;  // element (r = k, c = m)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const int r0 = (int)chunk * F4_RCHUNK;
 	const int rc = (nb - r0) < F4_RCHUNK ? (nb - r0) : F4_RCHUNK;
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 	const int srcA1 = 16 * m + 4 * (2 * ti + 1) + k;   // lane holding S(4ti+m, 4+k)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const int r0 = (int)chunk * F8_RCHUNK;
 	const int rc = (nb - r0) < F8_RCHUNK ? (nb - r0) : F8_RCHUNK;
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void factorodd_kernel(const FactorArgs a, cons
 	double *const tl = &s_l[wave][g][0];
 	double *const tu = &s_u[wave][g][0];
 
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const long rowlin = (long)chunk * RPB + wave * RPW + g;
 	const bool rowok = rowlin < (a.rows ? a.nrows : a.pat.nbrows);
 	const int irow = rowok ? (a.rows ? a.rows[rowlin] : (int)rowlin) : 0;

@@ -22,8 +22,8 @@
 // index load from HBM; all loads of a row step (KFIX predicated block passes, straight-line) are issued
 // before the first use, rows with more blocks finish in a remainder loop.  The bs x bs mat-vec is one
 // FMA per lane plus an all-reduce over the column bits and the block-slot bits on the VALU (lanes.hpp);
-// D is applied with one broadcast and a second all-reduce.  Workgroups are renumbered so that each XCD
-// sweeps one contiguous range of rows.
+// D is applied with one broadcast and a second all-reduce.  Workgroups are renumbered so that the XCDs
+// take turns on super-chunks of consecutive chunks (lanes.hpp, xcd_chunk).
 //
 // Async semantics: with xin == xout the sweep is chaotic relaxation -- iterate values written by other
 // waves of the same launch may or may not be observed (plain loads; stale L1/L2 lines are older
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 	const int gbase = lane & ~(G - 1);
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;  // rows [r0, r0 + rc)

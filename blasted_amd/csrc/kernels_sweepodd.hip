@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 	const bool hiA = cA != cx, hiB = cB != cx;
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;

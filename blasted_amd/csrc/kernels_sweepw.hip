@@ -19,7 +19,7 @@
 //    blocks in memory and is fetched by the same load instruction as block slot 0;
 //  * rhs is read and the result written as 16 bytes per lane (bs*8 contiguous bytes per row);
 //  * wave-uniform 64-bit bases + 32-bit per-lane byte offsets (halves address registers/arithmetic);
-//  * XCD-aware chunk numbering: each XCD sweeps one contiguous range of rows.
+//  * XCD-aware chunk numbering: the XCDs take turns on super-chunks of 16 chunks (lanes.hpp, xcd_chunk).
 #include "ctx.hpp"
 #include "lanes.hpp"
 #include "stage.hpp"
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	const int c = q / HB, h = q % HB;  // column of this lane's two entries, row pair (2h, 2h+1)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_contiguous_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
 	// rows of this chunk in index order: [r0, r0 + rc)
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
@@ -385,8 +385,11 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		   flight) fills every load pass whatever the row length (a 7-point row has 3 lower blocks: with  \
 		   two slots its second pass is half empty) -- bs=4 at 256^3: ILU pair -6 %, SGS pair -11 %, SpMV \
 		   -4 %, relaxation pass -5 %; bs=8 at 100^3: lower sweep 4.6 -> 6.3 TB/s, SpMV 5.1 -> 5.9 */      \
+		/* one slot, triangular sweeps at bs=4: two row steps in flight once the x segments came in one  \
+		   load per step (-1.5..2 % on both sweeps at 256^3, in every build of placement_variance.py) */   \
+		constexpr int UN1 = (BS == 4 && (PART == PART_LOWER || PART == PART_UPPER)) ? UV : 1;            \
 		if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                         \
-			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1>), dim3(grid), \
+			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \
 			                   dim3(256), 0, s, a);                                                    \
 		else                                                                                           \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UEFF, 2>), dim3(grid), \

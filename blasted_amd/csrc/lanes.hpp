@@ -5,14 +5,25 @@
 
 namespace bhip {
 
-// Contiguous range of workgroup ids per XCD (workgroups are dealt round-robin to the 8 XCDs): each XCD
-// then sweeps one contiguous range of block-rows, so its L2 serves the neighbour gathers and later
-// workgroups of the XCD observe earlier ones' updates.
-__device__ __forceinline__ unsigned xcd_contiguous_chunk(unsigned bid, unsigned nwg)
+// Which chunk of rows a workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs; the XCDs take
+// turns on super-chunks of XCD_SUPER consecutive chunks: workgroup (xcd, local) gets chunk
+// (local / S) * 8S + xcd * S + local % S.  Inside a super-chunk (2048 rows at 128 rows per chunk) an XCD's
+// L2 serves the near-neighbour gathers and later workgroups of the XCD observe earlier ones' updates,
+// while all XCDs stay inside one moving window of the matrix, like a single in-order sweep.  The first
+// version gave each XCD one contiguous eighth of the rows: same preconditioner quality (distance to the
+// exact solve after 3+3 sweeps 0.158 against 0.162), but eight streams an eighth of the buffers apart,
+// whose speed depended on where the driver had put the buffers -- in about half of the builds of the
+// 256^3 problem the upper sweep ran 7 % and the lower sweep 2-9 % slower than with this mapping, never
+// faster (profiles/r01l_xcd_mapping.txt).  Chunks beyond the last full group of 8S keep their own index.
+constexpr unsigned XCD_SUPER = 16;
+__device__ __forceinline__ unsigned xcd_chunk(unsigned bid, unsigned nwg)
 {
+	constexpr unsigned S = XCD_SUPER;
+	const unsigned full = nwg - nwg % (8u * S);
+	if (bid >= full)
+		return bid;
 	const unsigned xcd = bid & 7u, local = bid >> 3;
-	const unsigned base = nwg >> 3, rem = nwg & 7u;
-	return xcd * base + (xcd < rem ? xcd : rem) + local;
+	return (local / S) * (8u * S) + xcd * S + local % S;
 }
 
 template <int CTRL>

@@ -25,7 +25,7 @@ def main():
     p.set_matrix(m)
     p.ilu0_factorize(-1)
     ze = p.ilu0_apply(r, 1, mode=capi.LEVEL).clone()
-    for spec in ("interleave=0", "interleave=1"):
+    for spec in (sys.argv[3:] or ["interleave=0", "interleave=1"]):
         capi.set_tuning(spec)
         for s in (1, 3, 10, 30):
             p.ilu0_apply(r, s, out=z)
