@@ -51,6 +51,37 @@ __global__ __launch_bounds__(256) void read_chunk_kernel(const v2d *__restrict__
 		out[0] = acc;
 }
 
+// cache-policy variants of the chunked read: MODE 0 default, 1 nt, 2 sc0 sc1 (system scope), 3 sc0 sc1 nt, 4 sc1, 5 sc0
+template <int MODE>
+__global__ __launch_bounds__(256) void read_policy_kernel(const v2d *__restrict__ in, double *__restrict__ out, long n16,
+                                                        int per_wg)
+{
+	const long base = (long)blockIdx.x * per_wg;
+	double acc = 0;
+	for (int k = threadIdx.x; k < per_wg; k += 256) {
+		const long i = base + k;
+		if (i < n16) {
+			v2d v;
+			const v2d *ptr = in + i;
+			if (MODE == 0)
+				asm volatile("global_load_dwordx4 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			else if (MODE == 1)
+				asm volatile("global_load_dwordx4 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			else if (MODE == 2)
+				asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			else if (MODE == 3)
+				asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			else if (MODE == 4)
+				asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			else
+				asm volatile("global_load_dwordx4 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+			acc += v.x + v.y;
+		}
+	}
+	if (acc == 1.2345e300)
+		out[0] = acc;
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const v2d *__restrict__ in, v2d *__restrict__ out, long n16)
 {
 	const long stride = (long)gridDim.x * 256;
@@ -133,6 +164,10 @@ int main(int argc, char **argv)
 		t = time_ms([&] { hipLaunchKernelGGL((read_chunk_kernel<true>), dim3(grid), dim3(256), 0, 0, in, sink, n16, per_wg); });
 		std::printf("read  chunk %6d B/WG nontemp  %7u WGs: %6.3f ms  %.2f TB/s\n", per_wg * 16, grid, t, bytes / t / 1e9);
 	}
+#define POLICY(M, NAME) { const int per_wg = 4096; const unsigned grid = (unsigned)((n16 + per_wg - 1) / per_wg); \
+		const double t = time_ms([&] { hipLaunchKernelGGL((read_policy_kernel<M>), dim3(grid), dim3(256), 0, 0, in, sink, n16, per_wg); }); \
+		std::printf("read  chunk 64 KiB, one load in flight per lane, %-12s: %6.3f ms  %.2f TB/s\n", NAME, t, bytes / t / 1e9); }
+	POLICY(0, "default") POLICY(1, "nt") POLICY(2, "sc0 sc1") POLICY(3, "sc0 sc1 nt") POLICY(4, "sc1") POLICY(5, "sc0")
 	for (int wgs : {8192, 65536}) {
 		const double t = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(wgs), dim3(256), 0, 0, in, out, n16); });
 		std::printf("copy  grid-stride nontemp      %7d WGs: %6.3f ms  %.2f TB/s (read+write)\n", wgs, t, 2.0 * bytes / t / 1e9);
