@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "blockmatrices.hpp"
+#include "coomatrix.hpp"
 #include "solverfactory.hpp"
 
 using namespace blasted;
@@ -54,77 +55,20 @@ static Params parse(int argc, char **argv)
 	return p;
 }
 
+// Matrix Market input is the host library's (coomatrix.hpp), as in the reference's driver
+// (tests/testsolve.cpp:60-107)
 static std::vector<double> read_dense(const std::string &path)
 {
-	std::ifstream f(path);
-	if (!f) { std::cerr << "cannot open " << path << "\n"; std::exit(2); }
-	std::string line;
-	std::getline(f, line);
-	while (std::getline(f, line) && line[0] == '%') {}
-	std::istringstream hs(line);
-	long nr, nc;
-	hs >> nr >> nc;
-	std::vector<double> v((size_t)(nr * nc));
-	for (auto &x : v) f >> x;
-	return v;
+	const device_vector<double> v = readDenseMatrixMarket<double>(path);
+	return std::vector<double>(v.begin(), v.end());
 }
 
-// general coordinate Matrix-Market -> sparse (block-)row storage with ascending block columns
-static SRMatrixStorage<double, int> read_bsr(const std::string &path, const int bs, const bool rowmajor)
+template <int bs>
+static SRMatrixStorage<double, int> read_bsr(const std::string &path, const bool rowmajor)
 {
-	std::ifstream f(path);
-	if (!f) { std::cerr << "cannot open " << path << "\n"; std::exit(2); }
-	std::string line;
-	std::getline(f, line);
-	if (line.find("coordinate") == std::string::npos || line.find("general") == std::string::npos) {
-		std::cerr << "can only read general coordinate matrices\n";
-		std::exit(2);
-	}
-	while (std::getline(f, line) && line[0] == '%') {}
-	std::istringstream hs(line);
-	long nr, nc, nnz;
-	hs >> nr >> nc >> nnz;
-	assert(nr == nc && nr % bs == 0);
-	const int nb = (int)(nr / bs);
-	struct Ent { long key; int inblk; double v; };
-	std::vector<Ent> ents((size_t)nnz);
-	for (auto &e : ents) {
-		long i, j;
-		double v;
-		f >> i >> j >> v;
-		--i; --j;
-		const int r = (int)(i % bs), c = (int)(j % bs);
-		e.key = (i / bs) * nb + (j / bs);
-		e.inblk = rowmajor ? r * bs + c : c * bs + r;
-		e.v = v;
-	}
-	std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
-	std::vector<long> keys;
-	for (const auto &e : ents)
-		if (keys.empty() || keys.back() != e.key) keys.push_back(e.key);
-	const int nnzb = (int)keys.size();
-	SRMatrixStorage<double, int> m;
-	m.nbrows = nb; m.nnzb = nnzb; m.nbstored = nnzb;
-	m.browptr.resize(nb + 1); m.bcolind.resize(nnzb); m.vals.resize(nnzb * bs * bs);
-	m.diagind.resize(nb); m.browendptr.resize(nb);
-	for (int i = 0; i < nnzb * bs * bs; i++) m.vals[i] = 0;
-	for (int i = 0; i <= nb; i++) m.browptr[i] = 0;
-	size_t k = 0;
-	for (int b = 0; b < nnzb; b++) {
-		const int brow = (int)(keys[b] / nb), bcol = (int)(keys[b] % nb);
-		m.bcolind[b] = bcol;
-		m.browptr[brow + 1]++;
-		if (brow == bcol) m.diagind[brow] = b;
-		while (k < ents.size() && ents[k].key == keys[b]) {
-			m.vals[b * bs * bs + ents[k].inblk] += ents[k].v;
-			k++;
-		}
-	}
-	for (int i = 0; i < nb; i++) {
-		m.browptr[i + 1] += m.browptr[i];
-		m.browendptr[i] = m.browptr[i + 1];
-	}
-	return m;
+	COOMatrix<double, int> coo;
+	coo.readMatrixMarket(path);
+	return getSRMatrixFromCOO<double, int, bs>(coo, rowmajor ? "rowmajor" : "colmajor");
 }
 
 static double dot(const std::vector<double> &a, const std::vector<double> &b)
@@ -196,12 +140,12 @@ static int test_solve(const Params &params)
 	const bool rm = params.storageorder == "rowmajor";
 	SRMatrixView<double, int> *mat = nullptr;
 	if (bs == 1)
-		mat = new CSRMatrixView<double, int>(move_to_const<double, int>(read_bsr(params.mat_file, 1, false)));
+		mat = new CSRMatrixView<double, int>(move_to_const<double, int>(read_bsr<1>(params.mat_file, false)));
 	else if (rm)
-		mat = new BSRMatrixView<double, int, bs, RowMajor>(move_to_const<double, int>(read_bsr(params.mat_file, bs, true)));
+		mat = new BSRMatrixView<double, int, bs, RowMajor>(move_to_const<double, int>(read_bsr<bs>(params.mat_file, true)));
 	else
-		mat = new BSRMatrixView<double, int, bs, ColMajor>(move_to_const<double, int>(read_bsr(params.mat_file, bs, false)));
-	SRMatrixStorage<const double, const int> cmat = move_to_const<double, int>(read_bsr(params.mat_file, bs, rm));
+		mat = new BSRMatrixView<double, int, bs, ColMajor>(move_to_const<double, int>(read_bsr<bs>(params.mat_file, false)));
+	SRMatrixStorage<const double, const int> cmat = move_to_const<double, int>(read_bsr<bs>(params.mat_file, rm));
 	const std::vector<double> b = read_dense(params.b_file);
 	std::printf("Read matrix with %d (block-)rows, %d nonzero blocks, block size %d\n", cmat.nbrows, cmat.nnzb, bs);
 

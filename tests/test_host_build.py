@@ -27,7 +27,11 @@ def test_host_library_exports_reference_classes():
                 "blasted::AsyncBlockILU0_SRPreconditioner<double, int, 4, (blasted::StorageOptions)1>::apply(",
                 "blasted::AsyncBlockSGS_SRPreconditioner<double, int, 4, (blasted::StorageOptions)0>::apply_relax(",
                 "blasted::BJacobiSRPreconditioner<double, int, 4, (blasted::StorageOptions)0>::compute()",
-                "blasted::SRMatrixView<double, int>::gemv3("]:
+                "blasted::SRMatrixView<double, int>::gemv3(",
+                "blasted::COOMatrix<double, int>::readMatrixMarket(",
+                "blasted::COOMatrix<double, int>::convertToCSR() const",
+                "blasted::getSRMatrixFromCOO<double, int, 4>(",
+                "blasted::readDenseMatrixMarket<double>("]:
         assert sym in out, sym
 
 
@@ -56,3 +60,113 @@ def test_native_driver_fails_loudly_without_gpu():
                         "--x_file", os.path.join(g, "2dcyl1_x.mtx")], capture_output=True, text=True)
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr
+
+
+# ---- Matrix-Market route of the host library (coomatrix.hpp; reference include/coomatrix.hpp) ----------
+COO = os.path.join(ROOT, "tests", "cpp", "build", "coo_dump")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _coo_dump(path, bs, order, tmp_path):
+    import numpy as np
+    out = str(tmp_path / "m.bin")
+    subprocess.check_call([COO, path, str(bs), order, out])
+    raw = open(out, "rb").read()
+    nb, nnzb = np.frombuffer(raw, np.int32, 2)
+    o = 8
+    browptr = np.frombuffer(raw, np.int32, nb + 1, o); o += 4 * (nb + 1)
+    bcolind = np.frombuffer(raw, np.int32, nnzb, o); o += 4 * nnzb
+    diagind = np.frombuffer(raw, np.int32, nb, o); o += 4 * nb
+    vals = np.frombuffer(raw, np.float64, nnzb * bs * bs, o)
+    assert o + 8 * nnzb * bs * bs == len(raw)
+    return nb, nnzb, browptr, bcolind, diagind, vals
+
+
+@pytest.mark.parametrize("name,bs,order", [
+    ("small_block3_matrix", 3, "colmajor"), ("small_block3_matrix", 3, "rowmajor"),
+    ("2dcyl1", 4, "colmajor"), ("2dcyl1", 4, "rowmajor"), ("2dcyl1", 1, "colmajor"),
+    ("DK01R", 7, "rowmajor"), ("msc00726", 1, "colmajor"), ("msc00726", 2, "colmajor")])
+def test_coomatrix_matches_python_reader(name, bs, order, tmp_path):
+    """COOMatrix::readMatrixMarket + getSRMatrixFromCOO on the reference's own matrix files against the
+    Python reader the GPU tests use (blasted_amd/mtxio.py), bit for bit."""
+    import numpy as np
+    from blasted_amd import mtxio
+    path = os.path.join(GOLDEN, name + ".mtx")
+    nb, nnzb, browptr, bcolind, diagind, vals = _coo_dump(path, bs, order, tmp_path)
+    m = mtxio.read_mtx_bsr(path, bs, rowmajor=(order == "rowmajor"))
+    assert nb == m["nbrows"] and nnzb == len(m["bcolind"])
+    np.testing.assert_array_equal(browptr, m["browptr"])
+    np.testing.assert_array_equal(bcolind, m["bcolind"])
+    np.testing.assert_array_equal(diagind, m["diagind"])
+    np.testing.assert_array_equal(vals, m["vals"])
+    # ascending block columns inside every block-row (the reference's conversion does not guarantee it)
+    for i in range(nb):
+        assert np.all(np.diff(bcolind[browptr[i]:browptr[i + 1]]) > 0)
+
+
+def test_coomatrix_block_file_agrees_with_reference_bcoo_fixture(tmp_path):
+    """The reference ships the expected sorted column-major BSR form of small_block3_matrix.mtx
+    (tests/mat_ops/input/small_block3_matrix_sorted_bcolmajor.bcoo, tests/mat_ops/CMakeLists.txt:47-51:
+    header, browptr, 1-based block rows / columns, block values, diagonal positions); the library's
+    conversion reproduces it exactly."""
+    import numpy as np
+    nb, nnzb, browptr, bcolind, diagind, vals = _coo_dump(
+        os.path.join(GOLDEN, "small_block3_matrix.mtx"), 3, "colmajor", tmp_path)
+    tok = open(os.path.join(GOLDEN, "small_block3_matrix_sorted_bcolmajor.bcoo")).read().split()
+    nbr, nbc, nz = (int(t) for t in tok[:3])
+    assert (nb, nnzb) == (nbr, nz) and nbr == nbc
+    np.testing.assert_array_equal(browptr, np.array(tok[3:3 + nbr + 1], dtype=np.int32))
+    np.testing.assert_array_equal(bcolind, np.array(tok[4 + nbr + nz:4 + nbr + 2 * nz], dtype=np.int32) - 1)
+    v0 = 4 + nbr + 2 * nz
+    np.testing.assert_array_equal(vals, np.array(tok[v0:v0 + 9 * nz], dtype=np.float64))
+    np.testing.assert_array_equal(diagind, np.array(tok[v0 + 9 * nz:], dtype=np.int32))
+
+
+def test_coomatrix_unsorted_rows_and_empty_rows(tmp_path):
+    """Entries in arbitrary order, a block-row whose first stored entry is not in its first block, and
+    an empty scalar row: blocks still come out in ascending block-column order (reference quirk Q8 fixed)."""
+    import numpy as np
+    p = tmp_path / "u.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n% comment\n\n4 4 7\n"
+                 "1 4 14\n1 1 11\n2 2 22\n4 1 41\n4 4 44\n3 3 33\n1 3 13\n")
+    nb, nnzb, browptr, bcolind, diagind, vals = _coo_dump(str(p), 2, "rowmajor", tmp_path)
+    assert nb == 2 and nnzb == 4
+    np.testing.assert_array_equal(browptr, [0, 2, 4])
+    np.testing.assert_array_equal(bcolind, [0, 1, 0, 1])
+    np.testing.assert_array_equal(diagind, [0, 3])
+    np.testing.assert_array_equal(vals.reshape(4, 2, 2), [[[11, 0], [0, 22]], [[13, 14], [0, 0]],
+                                                          [[0, 0], [41, 0]], [[33, 0], [0, 44]]])
+    q = tmp_path / "e.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 5\n3 3 7\n")
+    nb, nnzb, browptr, bcolind, diagind, vals = _coo_dump(str(q), 1, "colmajor", tmp_path)
+    np.testing.assert_array_equal(browptr, [0, 1, 1, 2])
+    np.testing.assert_array_equal(diagind, [0, -1, 1])
+
+
+@pytest.mark.parametrize("text", [
+    "%%MatrixMarket matrix coordinate real symmetric\n2 2 1\n1 1 1\n",
+    "%%MatrixMarket matrix coordinate pattern general\n2 2 1\n1 1\n",
+    "%%MatrixMarket matrix array real general\n2 1\n1\n2\n",
+    "%%MatrixMarket matrix coordinate real\n2 2 1\n1 1 1\n",
+    "%%NotMatrixMarket matrix coordinate real general\n2 2 1\n1 1 1\n",
+    "%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1\n",
+    "%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1\n"])
+def test_coomatrix_rejects_what_the_reference_rejects(text, tmp_path):
+    """Non-coordinate, pattern and non-general files throw MatrixReadException as in the reference
+    (src/coomatrix.cpp:199-207); malformed files too (the reference aborts on some of them)."""
+    p = tmp_path / "bad.mtx"
+    p.write_text(text)
+    r = subprocess.run([COO, str(p), "1", "colmajor", str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 3 and "MatrixReadException" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_dense_matrix_market_reader(tmp_path):
+    import numpy as np
+    from blasted_amd import mtxio
+    path = os.path.join(GOLDEN, "2dcyl1_b.mtx")
+    out = str(tmp_path / "v.bin")
+    subprocess.check_call([COO, path, "dense", out])
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw, np.int64, 1)[0])
+    v = np.frombuffer(raw, np.float64, n, 8)
+    np.testing.assert_array_equal(v, np.asarray(mtxio.read_mtx_dense(path)).ravel())
