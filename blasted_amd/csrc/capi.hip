@@ -1305,6 +1305,9 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
 	return guarded([&] {
 		if (!dev_ptr || !gbps || reps < 1 || (reinterpret_cast<uintptr_t>(dev_ptr) & 15u))
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "measure_read_stream: 16-byte aligned device buffer, reps >= 1");
+		hipPointerAttribute_t attr;
+		BHIP_CHECK(hipPointerGetAttributes(&attr, dev_ptr));
+		BHIP_CHECK(hipSetDevice(attr.device));  // measure on the device that owns the buffer
 		double *sink = dev_alloc<double>(1);
 		hipEvent_t e0, e1;
 		BHIP_CHECK(hipEventCreate(&e0));
