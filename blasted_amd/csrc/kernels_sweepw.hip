@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 }
 
 struct Variant {
-	int rchunk = 128, nt = 1, unr = 2, enabled = 1;
+	int rchunk = 128, nt = 1, unr = 1, enabled = 1;
 	int nb1 = 1;  // one block slot per row (bs=4: 8 lanes per row, 8 rows per wave; bs=8: 32 lanes, 2 rows); 0 = two slots, 3 = triangular sweeps only
 };
 
@@ -348,7 +348,7 @@ static Variant parse_variant(const char *e)
 		v.enabled = 0;
 		return v;
 	}
-	int r = 128, nt = 1, unr = 2, nb1 = 1;
+	int r = 128, nt = 1, unr = 1, nb1 = 1;
 	const int got = std::sscanf(e, "r%d,nt%d,u%d,s%d", &r, &nt, &unr, &nb1);
 	if (got >= 3) {
 		v.rchunk = r;
@@ -385,8 +385,11 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		   flight) fills every load pass whatever the row length (a 7-point row has 3 lower blocks: with  \
 		   two slots its second pass is half empty) -- bs=4 at 256^3: ILU pair -6 %, SGS pair -11 %, SpMV \
 		   -4 %, relaxation pass -5 %; bs=8 at 100^3: lower sweep 4.6 -> 6.3 TB/s, SpMV 5.1 -> 5.9 */      \
-		/* one slot, triangular sweeps at bs=4: two row steps in flight once the x segments came in one  \
-		   load per step (-1.5..2 % on both sweeps at 256^3, in every build of placement_variance.py) */   \
+		/* one slot, triangular sweeps at bs=4: "u2" = two row steps in flight.  -1.5..2 % time on both  \
+		   sweeps at 256^3 in every build of placement_variance.py -- but more rows in flight read more    \
+		   stale neighbours: the error after 3+3 / 10+10 sweeps rises from 0.162 / 5.6e-4 to 0.190 /       \
+		   9.8e-4, i.e. the contraction per sweep from 0.444 to 0.471 = 8 % more sweeps for the same       \
+		   accuracy.  The default is therefore u1. */                                                      \
 		constexpr int UN1 = (BS == 4 && (PART == PART_LOWER || PART == PART_UPPER)) ? UV : 1;            \
 		if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                         \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \

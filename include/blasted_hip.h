@@ -181,7 +181,8 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
 
 /* ---- tuning hook (process-wide; measurements only).  spec: NULL = default, "generic" = always the
  * generic kernel family, or "r<128|256>,nt<0|1>,u<1|2>[,s<1|2|3>]" for the tuned bs=4/8 kernel (s: block
- * slots per row at bs=4 -- 1 (default), 2, or 3 = one slot for the triangular sweeps only); the same strings
+ * slots per row at bs=4 -- 1 (default), 2, or 3 = one slot for the triangular sweeps only; u: row steps in
+ * flight for the bs=4 triangular sweeps -- 1 (default; best accuracy per sweep) or 2 (2 % faster sweeps)); the same strings
  * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
  * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
  * "factorodd=0" / "factorodd=1": tuned bs=5/7 factorisation kernel off / on (BLASTED_HIP_FACTORODD).

@@ -100,7 +100,7 @@ def main():
         p.close()
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepwr=1", "factorodd=1", "factor4=1", "factor8=1", "gunroll=0",
-                 "r128,nt1,u2,s1"):
+                 "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
     for k in sorted(worst):

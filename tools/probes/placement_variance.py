@@ -12,7 +12,7 @@ from blasted_amd import capi, workloads as W  # noqa: E402
 
 dev = torch.device("cuda:0")
 grid = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-VARIANTS = [v for v in sys.argv[2:] if not v.startswith("n=")] or ["r128,nt1,u2,s1"]
+VARIANTS = [v for v in sys.argv[2:] if not v.startswith("n=")] or ["r128,nt1,u1,s1"]
 NAPPLY = int(([v[2:] for v in sys.argv[2:] if v.startswith("n=")] or ["12"])[0])
 spacers = [0, 0, 1 << 20, 3 << 20, 64 << 20, (1 << 30) + (5 << 20), 0, 7 << 20, 300 << 20, 0, (2 << 30) + (11 << 20), 33 << 20]
 for rnd, sp in enumerate(spacers):
