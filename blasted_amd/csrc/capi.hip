@@ -363,10 +363,22 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 	return launch_level_sweep(a, part, post, dsrc, ls, p->stream);
 }
 
-// tuning ("interleave=1"): rows of one step of the bs=4/8 column-major sweep are taken a step count apart,
-// so a row's predecessor belongs to the previous step: Gauss-Seidel-like along a chunk.  256^3, 3+3 sweeps:
-// distance to the exact solves 0.164 -> 0.061, but 10.1 -> 11.5 ms (scattered rows); off by default.
-static int g_interleave = 0;
+// "interleave=1" (environment BLASTED_HIP_INTERLEAVE=1): the rows a workgroup of the bs=4/8 column-major sweep
+// computes side by side are taken a step count apart, so a row's predecessor belongs to the previous step
+// (already stored) instead of to the same step (stale): Gauss-Seidel-like along a chunk, as the reference's
+// threads are inside their chunks.  256^3 bs=4, distance to the exact solves after 3+3 / 10+10 sweeps
+// 0.162 / 5.6e-4 -> 0.063 / 1.6e-5: contraction per sweep 0.444 -> 0.306, i.e. 1.46x fewer sweeps for the same
+// accuracy, at +13..15 % time per sweep -- the better preconditioner per unit of time, and the slower one
+// per sweep, which is what the headline metric counts: off by default, on for accuracy per second.
+// Where the +15 % comes from (round 1, tools/probes): the timing-only variant without gathers pays +16 % for the
+// 32-byte rhs / result pieces a step now takes 4 rows apart; storing the triangles in sweep order does not
+// help (the value stream was not the problem); and sweeping the symmetrically permuted system, on which every
+// access is contiguous again, still pays +10 % per sweep pair -- fresh neighbours are lines another wave has
+// just written -- plus two vector permutation passes per application.  Both were built, measured and removed.
+static int g_interleave = [] {
+	const char *e = std::getenv("BLASTED_HIP_INTERLEAVE");
+	return (e && e[0] == '1') ? 1 : 0;
+}();
 
 static SweepArgs base_args(blasted_hip_prec p)
 {
