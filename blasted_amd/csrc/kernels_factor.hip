@@ -534,6 +534,10 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	// (Tried for bs = 5 / 7: the tuned pair-layout kernel per level plus a launch that inverts the level's
 	// diagonal blocks.  Two launches per level cost more than the on-the-fly inverses save: 72.8 ms
 	// instead of 52.7 ms on the unstructured bs=5 case, 21.8 against 22.1 ms at bs=7.)
+	// (Tried: the 766 launches of the 256^3 problem as one instantiated hipGraph.  On a private stream the
+	// level loop takes 22.0 ms instead of ~23.7 ms -- the kernels themselves are 21.4 ms, the rest of the
+	// 29.6 ms call is the initial copy of the values and the final inversion of the diagonal blocks -- and
+	// launched into the null stream, which is what torch and the tests hand over, it gains nothing.)
 	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels are inverted on the fly
 	for (int l = 0; l < ls.nlevels; l++) {
 		a.rows = ls.rows + ls.ptr[l];
