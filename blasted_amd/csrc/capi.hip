@@ -694,12 +694,19 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		p->scaled = use_scaling != 0;
 		const double *scale = use_scaling ? p->scale : nullptr;
 
-		double *dscratch = nullptr;
-		if (fact_init == BLASTED_HIP_INIT_F_SGS)
-			dscratch = ensure(p->dblocks, (long)pat.nbrows * pat.bs * pat.bs);
-		launch_fact_init(pat, p->vals, scale, fact_init, p->iluvals, dscratch, p->stream);
-		if (fact_init == BLASTED_HIP_INIT_F_SGS)
-			p->jacobi_done = false;  // dblocks was used as scratch
+		// The exact in-order factorisation writes every entry before anything reads it (an entry needs earlier
+		// entries of its own row and rows of earlier levels only), so its result does not depend on the initial
+		// guess: the 15 GB initialisation pass (4.4 ms of 29.6 at 256^3 bs=4) is skipped unless the initial
+		// remainder is asked for.
+		const bool needs_init = !(nbuildsweeps < 0 && !precinfo);
+		if (needs_init) {
+			double *dscratch = nullptr;
+			if (fact_init == BLASTED_HIP_INIT_F_SGS)
+				dscratch = ensure(p->dblocks, (long)pat.nbrows * pat.bs * pat.bs);
+			launch_fact_init(pat, p->vals, scale, fact_init, p->iluvals, dscratch, p->stream);
+			if (fact_init == BLASTED_HIP_INIT_F_SGS)
+				p->jacobi_done = false;  // dblocks was used as scratch
+		}
 
 		FactorArgs fa;
 		fa.pat = pat;

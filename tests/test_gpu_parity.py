@@ -492,6 +492,30 @@ def test_sequential_variants_are_exact(golden, case):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "msc_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4"])
+def test_exact_factorisation_ignores_the_stored_factor(golden, case):
+    """The exact in-order factorisation skips the initialisation pass (every entry is written before it is
+    read): with the factor storage poisoned by NaNs beforehand the result is bit-identical, whatever the
+    initialisation type, and equal to the pass that did run the initialisation (compute_info=True)."""
+    import ctypes as C
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL)
+    f0 = p.get_iluvals()
+    assert np.all(np.isfinite(f0))
+    poison = np.full(f0.size, np.nan)
+    for init in (capi.INIT_F_ORIGINAL, capi.INIT_F_SGS, capi.INIT_F_ZERO):
+        rc = capi.lib().blasted_hip_buffer_upload(C.c_void_p(p.iluvals_device_ptr()), poison.ctypes.data_as(C.c_void_p),
+                                                  C.c_ulong(poison.nbytes))
+        assert rc == 0
+        assert np.all(np.isnan(p.get_iluvals()))
+        p.ilu0_factorize(-1, init=init)
+        assert np.array_equal(p.get_iluvals(), f0)
+    info = p.ilu0_factorize(-1, init=capi.INIT_F_ORIGINAL, compute_info=True)
+    assert np.array_equal(p.get_iluvals(), f0) and np.all(np.isfinite(info))
+    p.close()
+
+
 # ---------------------------------------------------------------------------- Jacobi relaxation
 
 @pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "msc_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4"])
