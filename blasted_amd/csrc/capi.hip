@@ -717,6 +717,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.upperp = p->upperp;
 		fa.rows = nullptr;
 		fa.nrows = 0;
+		fa.diag_inverted = 0;
 		fa.dinv_scratch = nullptr;
 		if (pat.bs >= 5)
 			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * pat.bs * pat.bs);
@@ -739,6 +740,10 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 			Phase ph(p, 0);
 			fa.in = p->iluvals;
 			fa.out = p->iluvals;
+			// a diagonal block is final once its row is done: store it inverted right away (no inverse per
+			// dependent lower block, no inversion pass at the end) -- unless the remainder, which is defined
+			// on the un-inverted factor, is asked for
+			fa.diag_inverted = (pat.bs > 1 && !precinfo) ? 1 : 0;
 			ph.launches = launch_factor_levels(fa, need_levels(p), p->stream);
 			ph.done();
 		} else {
@@ -775,7 +780,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		}
 
 		// block version only: invert diagonal blocks in place, src/async_blockilu_factor.cpp:143-146
-		if (pat.bs > 1) {
+		if (pat.bs > 1 && !fa.diag_inverted) {
 			Phase ph(p, 2);
 			launch_invert_diag_blocks(pat, p->iluvals, 1, p->iluvals, 1, p->stream);
 			ph.launches = 1;

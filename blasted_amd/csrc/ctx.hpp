@@ -122,6 +122,8 @@ struct FactorArgs {
 	double *dinv_scratch;   // optional nbrows*bs*bs scratch (bs=8 tuned path: inverted diagonal blocks)
 	const int *rows;        // optional row list (level-scheduled exact factorisation), else all rows
 	int nrows;              // length of `rows`
+	int diag_inverted;      // exact factorisation, bs > 1: diagonal blocks are stored inverted as soon as they are
+	                        // final, and lower blocks multiply with the stored inverse (general kernel only)
 };
 
 // kernels_sweep.hip

@@ -180,12 +180,18 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 				if (BS == 1)
 					res = s / dv;
 				else {
-					const double inv = group_inverse<BS, BSP>(dv, gbase, r, c);
+					const double inv = a.diag_inverted ? dv : group_inverse<BS, BSP>(dv, gbase, r, c);
 					res = group_gemm<BS, BSP>(s, inv, gbase, r, c);
 				}
 			}
 			if (active)
 				a.out[(long)jpos * BS2 + e] = res;
+		} else if (BS > 1 && a.diag_inverted && irow == col) {
+			// exact factorisation: this diagonal block is final -- store its inverse, the form every later
+			// reader (lower blocks of later rows, the triangular solves) wants
+			const double inv = group_inverse<BS, BSP>(s, gbase, r, c);
+			if (active)
+				a.out[(long)jpos * BS2 + e] = inv;
 		} else if (active) {
 			a.out[(long)jpos * BS2 + e] = s;
 		}
@@ -538,7 +544,7 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	// level loop takes 22.0 ms instead of ~23.7 ms -- the kernels themselves are 21.4 ms, the rest of the
 	// 29.6 ms call is the initial copy of the values and the final inversion of the diagonal blocks -- and
 	// launched into the null stream, which is what torch and the tests hand over, it gains nothing.)
-	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels are inverted on the fly
+	a.dinv_scratch = nullptr;  // diagonal blocks of earlier levels: inverted on the fly, or stored inverted (diag_inverted)
 	for (int l = 0; l < ls.nlevels; l++) {
 		a.rows = ls.rows + ls.ptr[l];
 		a.nrows = ls.ptr[l + 1] - ls.ptr[l];
