@@ -540,6 +540,12 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	// (Tried for bs = 5 / 7: the tuned pair-layout kernel per level plus a launch that inverts the level's
 	// diagonal blocks.  Two launches per level cost more than the on-the-fly inverses save: 72.8 ms
 	// instead of 52.7 ms on the unstructured bs=5 case, 21.8 against 22.1 ms at bs=7.)
+	// (Tried: a row-at-once kernel that fetches everything final before the level -- indices, A blocks, pair
+	// lists, upper operands, inverted diagonals -- up front and runs the row's recurrence from registers and
+	// LDS, to shorten the ~20 serialised loads of a row.  Bit-identical, and no faster: 21.9 against 20.2 ms,
+	// per-level times 5.3 / 28.8 / 53 us (min / mean / max) against 4.2 / 28 / 49.  The levels are bound by
+	// throughput (1.3 ns per row = 2.1 TB/s of 8-byte-per-lane loads), not by the dependent chain; the lever
+	// is the MFMA kernel's 16-byte layout on row lists, not latency.)
 	// (Tried: the 766 launches of the 256^3 problem as one instantiated hipGraph.  On a private stream the
 	// level loop takes 22.0 ms instead of ~23.7 ms -- the kernels themselves are 21.4 ms, the rest of the
 	// 29.6 ms call is the initial copy of the values and the final inversion of the diagonal blocks -- and
