@@ -112,6 +112,21 @@ def test_invalid_patterns_are_rejected():
     assert ei.value.code == capi.ENOTIMPL
 
 
+def test_measure_read_stream_reports_a_plausible_rate():
+    """The measurement aid behind bench.py's roofline.measured_read_stream_gbps: a 256 MB buffer streams at
+    well above 1 TB/s and below the 8 TB/s peak; misaligned and null buffers are rejected."""
+    import ctypes as C
+    import torch
+    x = torch.zeros(1 << 25, dtype=torch.float64, device="cuda")
+    g = capi.measure_read_stream(x, reps=5)
+    assert 1000.0 < g < 8000.0, g
+    out = C.c_double(0.0)
+    rc = capi.lib().blasted_hip_measure_read_stream(C.c_void_p(x.data_ptr() + 8), C.c_ulong(1 << 20), 1, C.byref(out))
+    assert rc == capi.EINVAL
+    rc = capi.lib().blasted_hip_measure_read_stream(C.c_void_p(0), C.c_ulong(1 << 20), 1, C.byref(out))
+    assert rc == capi.EINVAL
+
+
 # ---------------------------------------------------------------------------- SpMV (K11)
 
 @pytest.mark.parametrize("bs,rowmajor", [(1, False), (7, True), (7, False)])
