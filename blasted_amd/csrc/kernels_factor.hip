@@ -546,6 +546,11 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	// per-level times 5.3 / 28.8 / 53 us (min / mean / max) against 4.2 / 28 / 49.  The levels are bound by
 	// throughput (1.3 ns per row = 2.1 TB/s of 8-byte-per-lane loads), not by the dependent chain; the lever
 	// is the MFMA kernel's 16-byte layout on row lists, not latency.)
+	// (Tried: the matrix-core kernel on row lists -- factor4_kernel's operand layouts and MFMA products, one
+	// row per block slot, the row's finished lower blocks kept in LDS: 19.96 ms against 20.2 ms.  Neither the
+	// dependent chain nor the block arithmetic bounds a level; its rows are scattered over the natural-order
+	// storage (a wavefront i+j+k = const), every operand is a lone 128-byte access, and ~2.2 TB/s is what that
+	// pattern gets.  A level-ordered copy of the factor *and* its position lists would be the lever.)
 	// (Tried: the 766 launches of the 256^3 problem as one instantiated hipGraph.  On a private stream the
 	// level loop takes 22.0 ms instead of ~23.7 ms -- the kernels themselves are 21.4 ms, the rest of the
 	// 29.6 ms call is the initial copy of the values and the final inversion of the diagonal blocks -- and
