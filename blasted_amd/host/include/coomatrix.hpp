@@ -1,3 +1,3 @@
 // reference header name (include/coomatrix.hpp)
 #pragma once
-#include "blasted/coomatrix.hpp"
+#include "blasted/mmio.hpp"

@@ -1,6 +1,6 @@
-// coomatrix.cpp -- Matrix-Market input and COO -> CSR/BSR conversion (see blasted/coomatrix.hpp for the
-// reference surface this mirrors and the deliberate differences).
-#include "blasted/coomatrix.hpp"
+// mmio.cpp -- Matrix-Market input and COO -> CSR/BSR conversion (see blasted/mmio.hpp for the reference
+// surface this provides and the deliberate differences).
+#include "blasted/mmio.hpp"
 
 #include <algorithm>
 #include <fstream>
