@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end effect of the preconditioner variants: right-preconditioned BiCGStab (device vectors, torch
 for the vector algebra, this library for SpMV and the preconditioner) on the block-inflated 3-D Poisson
-matrix (Poisson (x) one fixed block) -- iterations and time to a relative residual of 1e-8.  usage: solve_compare.py [n=160] [bs=4]"""
+matrix (Poisson (x) one fixed block) -- iterations and time to a relative residual of 1e-8.  usage: solve_compare.py [n=160] [bs=4] [tuning strings ...]
+(with tuning strings, e.g. interleave=1, only the asynchronous variants are run)"""
 import sys
 import time
 
@@ -75,6 +76,13 @@ def main():
         ("sapilu0: async 3 build, exact apply", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
         ("seqilu0: exact build, exact apply", lambda: p.ilu0_factorize(-1), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
     ]
+    specs = sys.argv[3:]
+    for spec in specs:
+        capi.set_tuning(spec)
+    if specs:
+        print("tuning: " + " ".join(specs))
+        variants = [v for v in variants if "async" in v[0] and "sapilu0" not in v[0]]
+        variants.insert(3, ("ilu0 async 3 build + 5 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 5)))
     for name, setup, M in variants:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
