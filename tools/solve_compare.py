@@ -73,10 +73,15 @@ def main():
         ("ilu0 async 3 build + 1 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1)),
         ("ilu0 async 3 build + 3 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 3)),
         ("ilu0 async 3 build + 10 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 10)),
+        ("ilu0 async 3 build + 3 SYNCHRONOUS (Jacobi) apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 3, mode=capi.JACOBI_SYNC)),
+        ("ilu0 async 3 build + 10 SYNCHRONOUS (Jacobi) apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 10, mode=capi.JACOBI_SYNC)),
         ("sapilu0: async 3 build, exact apply", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
         ("seqilu0: exact build, exact apply", lambda: p.ilu0_factorize(-1), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
     ]
-    specs = sys.argv[3:]
+    only = [a[5:] for a in sys.argv[3:] if a.startswith("only=")]
+    specs = [a for a in sys.argv[3:] if not a.startswith("only=")]
+    if only:
+        variants = [v for v in variants if any(o in v[0] for o in only)]
     for spec in specs:
         capi.set_tuning(spec)
     if specs:
