@@ -496,6 +496,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		dev_free(p->iluvals);
 		dev_free(p->iluvals2);
 		dev_free(p->finv);
+		dev_free(p->fdiag);
 		dev_free(p->scale);
 		dev_free(p->ytemp);
 		dev_free(p->yperm);
@@ -667,6 +668,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		check_mode(mode);
 		p->fac_lvl.valid = false;
 		p->fac_nat.valid = false;
+		p->fdiag_valid = false;
 		if (mode == BLASTED_HIP_LEVEL)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
 			                              "points; the exact factorisation is nbuildsweeps < 0");
@@ -814,9 +816,15 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		const bool jac = mode == BLASTED_HIP_JACOBI_SYNC;
 		p->y_in_level_order = false;  // this call rewrites ytemp
 
+		// Synchronous sweeps start from a known iterate, so their first sweep needs no matrix: from y0 = 0 the
+		// lower sweep gives y1 = S r exactly, and from z0 = 0 the upper one gives z1 = D^-1 y, a product with
+		// the diagonal blocks alone (bit-identical: the skipped products are all with zeros).  3+3 synchronous
+		// sweeps then cost two lower sweeps, one diagonal pass and two upper sweeps.
+		const bool skip_first = jac && napplysweeps >= 1;
+
 		// y := 0 (both init types), src/solverops_ilu0.cpp:83-94.  The prologue z := S r is fused: the
 		// lower sweeps read r (times scale) directly as their right-hand side.
-		{
+		if (!skip_first) {
 			Phase ph(p, 2);
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
 			ph.launches = 1;
@@ -831,8 +839,24 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		if (compact)
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
-		double *y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, nullptr,
-		                       napplysweeps, mode, 0);
+		double *y;
+		if (skip_first) {
+			const double *y1 = dr;  // y1 = S r
+			if (p->scaled) {
+				Phase ph(p, 2);
+				BHIP_CHECK(hipMemcpyAsync(yother, dr, nbytes, hipMemcpyDeviceToDevice, p->stream));
+				launch_scale_vec(yother, p->scale, n, p->stream);
+				ph.launches = 2;
+				ph.done();
+				y1 = yother;
+			}
+			if (napplysweeps == 1) {
+				BHIP_CHECK(hipMemcpyAsync(p->ytemp, y1, nbytes, hipMemcpyDeviceToDevice, p->stream));
+				y = p->ytemp;
+			} else
+				y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, y1, napplysweeps - 1, mode, 0);
+		} else
+			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, nullptr, napplysweeps, mode, 0);
 		double *yfree = (y == p->ytemp) ? yother : p->ytemp;  // Jacobi mode: the non-final y buffer
 
 		// z := y or z := 0, then upper sweeps, src/solverops_ilu0.cpp:110-141
@@ -864,6 +888,26 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 				ph.done();
 			}
 			run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, nullptr, first_in, napplysweeps, mode, 1);
+		} else if (apply_init == BLASTED_HIP_INIT_A_ZERO && !scalar) {
+			// first sweep from z0 = 0: z1 = D^-1 y through the contiguous copy of the factor's diagonal blocks
+			if (!p->fdiag_valid) {
+				ensure(p->fdiag, (long)p->pat.nbrows * p->pat.bs * p->pat.bs);
+				launch_gather_diag_blocks(p->pat, p->iluvals, p->fdiag, p->stream);
+				p->fdiag_valid = true;
+			}
+			SweepArgs d = base_args(p);
+			d.vals = p->iluvals;
+			d.dvals = p->fdiag;
+			d.rhs = y;
+			run_sweeps(p, d, PART_NONE, POST_D_SUB, D_DBLOCKS, dz, nullptr, y, 1, BLASTED_HIP_ASYNC, 1);
+			if (napplysweeps > 1) {
+				double *zo = ensure(p->tmp[1], n);  // sweep 2: dz -> zo ; sweep 3: zo -> dz ; ...
+				zfinal = run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, zo, nullptr, napplysweeps - 1, mode, 1);
+				if (zfinal != dz) {
+					BHIP_CHECK(hipMemcpyAsync(dz, zfinal, nbytes, hipMemcpyDeviceToDevice, p->stream));
+					zfinal = dz;
+				}
+			}
 		} else {
 			const double *first_in = y;
 			if (apply_init == BLASTED_HIP_INIT_A_ZERO) {
@@ -966,7 +1010,11 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		}
 		const bool reinit = apply_init == BLASTED_HIP_INIT_A_JACOBI || apply_init == BLASTED_HIP_INIT_A_ZERO;
 		p->y_in_level_order = false;  // this call rewrites ytemp
-		if (reinit) {  // src/solverops_sgs.cpp:57-60
+		// Synchronous sweeps from a zero iterate need no matrix for their first sweep (as in ilu0_apply): the
+		// forward one is y1 = D^-1 r, the backward one z1 = y -- bit-identical, the skipped products are with zeros.
+		const bool skip_fwd = jac && reinit && napplysweeps >= 1;
+		const bool skip_bwd = jac && apply_init == BLASTED_HIP_INIT_A_ZERO && napplysweeps >= 1;
+		if (reinit && !skip_fwd) {  // src/solverops_sgs.cpp:57-60
 			Phase ph(p, 2);
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
 			ph.launches = 1;
@@ -979,11 +1027,13 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		a.rhs = dr;
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0;
+		if (skip_fwd)
+			run_sweeps(p, a, PART_NONE, POST_D_SUB, D_DBLOCKS, p->ytemp, nullptr, dr, 1, BLASTED_HIP_ASYNC, 0);
 		if (compact)
 			compact_args(p, false, a, p->vals, p->mat_nat);
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y = run_sweeps(p, a, PART_LOWER, POST_D_SUB, D_DBLOCKS, p->ytemp, yother, nullptr,
-		                       napplysweeps, mode, 0);
+		                       skip_fwd ? napplysweeps - 1 : napplysweeps, mode, 0);
 		if (y != p->ytemp) {
 			BHIP_CHECK(hipMemcpyAsync(p->ytemp, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
 			y = p->ytemp;
@@ -997,8 +1047,9 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		if (compact)
 			compact_args(p, true, a, p->vals, p->mat_nat);
 		const double *first_in = nullptr;
-		if (apply_init == BLASTED_HIP_INIT_A_JACOBI) {
-			if (napplysweeps == 0)
+		const int nbwd = skip_bwd ? napplysweeps - 1 : napplysweeps;  // skip_bwd: z1 = y, continue as from z0 = y
+		if (apply_init == BLASTED_HIP_INIT_A_JACOBI || skip_bwd) {
+			if (nbwd == 0)
 				BHIP_CHECK(hipMemcpyAsync(dz, y, nbytes, hipMemcpyDeviceToDevice, p->stream));
 			else
 				first_in = y;
@@ -1009,14 +1060,13 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 			ph.done();
 		}
 		double *zo = jac ? ensure(p->tmp[1], n) : nullptr;
-		if (jac && !first_in && napplysweeps > 0) {
+		if (jac && !first_in && nbwd > 0) {
 			// synchronous sweeps need the initial z in a buffer that is not written by sweep 1
 			BHIP_CHECK(hipMemcpyAsync(p->tmp[0] ? p->tmp[0] : ensure(p->tmp[0], n), dz, nbytes,
 			                          hipMemcpyDeviceToDevice, p->stream));
 			first_in = p->tmp[0];
 		}
-		double *zfinal = run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, zo, first_in,
-		                            napplysweeps, mode, 1);
+		double *zfinal = run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, zo, first_in, nbwd, mode, 1);
 		if (zfinal != dz)
 			BHIP_CHECK(hipMemcpyAsync(dz, zfinal, nbytes, hipMemcpyDeviceToDevice, p->stream));
 		finish_out(p, z, dz, loc);

@@ -182,6 +182,7 @@ void run_diag_dominance(const Pattern &pat, const double *fvals, double *dev_scr
 // kernels_aux.hip
 long run_ilu_positions(const Pattern &pat, int **posptr, int **lowerp, int **upperp, hipStream_t s);
 void launch_scale_vec(double *z, const double *scale, long n, hipStream_t s);
+void launch_gather_diag_blocks(const Pattern &pat, const double *vals, double *dst, hipStream_t s);
 void launch_read_stream(const void *buf, unsigned long nbytes, double *sink, hipStream_t s);
 double run_diff_norm(const double *x, const double *y, long n, double *dev_scratch, hipStream_t s);
 int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len);
@@ -220,6 +221,8 @@ struct blasted_hip_prec_s {
 
 	double *iluvals = nullptr, *iluvals2 = nullptr;
 	double *finv = nullptr;  // inverted diagonal blocks of the current iterate (bs=8 factorisation sweeps)
+	double *fdiag = nullptr;  // the factor's (inverted) diagonal blocks, contiguous: first synchronous upper sweep
+	bool fdiag_valid = false;
 	double *scale = nullptr;
 	bool factored = false, scaled = false;
 	double *ytemp = nullptr;

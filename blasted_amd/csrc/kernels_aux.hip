@@ -221,6 +221,26 @@ int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len)
 	return h[0];
 }
 
+// dst[i] = vals[diagind[i]] per block-row: the diagonal blocks of a factor as one contiguous array
+__global__ __launch_bounds__(256) void gather_diag_blocks_kernel(const Pattern pat, const double *__restrict__ vals,
+                                                                double *__restrict__ dst)
+{
+	const long bs2 = (long)pat.bs * pat.bs;
+	const long i = (long)blockIdx.x * 256 + threadIdx.x;
+	if (i < (long)pat.nbrows * bs2) {
+		const long row = i / bs2;
+		dst[i] = vals[(long)pat.diagind[row] * bs2 + (i - row * bs2)];
+	}
+}
+
+void launch_gather_diag_blocks(const Pattern &pat, const double *vals, double *dst, hipStream_t s)
+{
+	const long n = (long)pat.nbrows * pat.bs * pat.bs;
+	if (n == 0)
+		return;
+	hipLaunchKernelGGL(gather_diag_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pat, vals, dst);
+}
+
 // Read-only stream over a buffer in the shape of the sweeps' value stream: a workgroup takes 64 KiB
 // contiguous, 16 bytes per lane, non-temporal (blasted_hip_measure_read_stream).
 __global__ __launch_bounds__(256) void read_stream_kernel(const double *__restrict__ in, double *__restrict__ sink,
