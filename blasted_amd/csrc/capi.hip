@@ -380,6 +380,10 @@ static int g_interleave = [] {
 	return (e && e[0] == '1') ? 1 : 0;
 }();
 
+// tuning ("relaxsplit=0|1"): exact relaxation passes as product + exact triangular solve (default) or as one
+// whole-row exact kernel
+static int g_relax_split = 1;
+
 static SweepArgs base_args(blasted_hip_prec p)
 {
 	SweepArgs a;
@@ -1101,6 +1105,8 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 		a.rhs = db;
 		double *other = (mode != BLASTED_HIP_ASYNC) ? ensure(p->tmp[0], n) : nullptr;
 		double *cur = dx;
+		if (mode == BLASTED_HIP_LEVEL)
+			restore_ytemp(p);  // the split exact passes use the level-ordered y buffer as scratch
 		for (int step = 0; step < maxits; step++) {
 			for (int dir = 0; dir < (symmetric ? 2 : 1); dir++) {
 				a.descending = dir;
@@ -1108,7 +1114,47 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 				Phase ph(p, dir);
 				a.xin = cur;
 				a.xout = o;
-				if (mode == BLASTED_HIP_LEVEL) {  // exact ascending / descending Gauss-Seidel pass
+				if (mode == BLASTED_HIP_LEVEL && g_relax_split) {
+					// exact ascending / descending Gauss-Seidel pass, split into a product with the other
+					// triangle taken from the previous iterate (full-speed out-of-place sweep) and an exact
+					// triangular solve (the streaming exact kernels of the SGS application):
+					//   ascending : (D + L) x_new = b - U x_old        descending: (D + U) x_new = b - L x_old
+					o = (cur == dx) ? other : dx;
+					double *t = ensure(p->tmp[1], n);
+					SweepArgs m = base_args(p);
+					m.vals = p->vals;
+					m.rhs = db;
+					m.xin = cur;
+					m.xout = t;
+					m.descending = dir;
+					launch_sweep(m, dir == 0 ? PART_UPPER : PART_LOWER, POST_SUB, D_NONE, p->stream);
+					int nl = 1;
+					SweepArgs e = base_args(p);
+					e.vals = p->vals;
+					e.dvals = p->dblocks;
+					e.descending = dir;
+					if (dir == 0) {
+						e.rhs = t;  // x_new = D^-1 (t - L x_new)
+						nl += exact_pass(p, e, PART_LOWER, POST_D_SUB, D_DBLOCKS, o, nullptr);
+						if (p->y_in_level_order) {  // the level-ordered form left its result in yperm
+							launch_level_unpermute(p->levels, p->pat.bs, p->yperm, o, p->stream);
+							p->y_in_level_order = false;
+							nl++;
+						}
+					} else {
+						double *yd = ensure(p->tmp[2], n);  // x_new = D^-1 t - D^-1 U x_new
+						SweepArgs j = base_args(p);
+						j.vals = p->vals;
+						j.dvals = p->dblocks;
+						j.rhs = t;
+						j.xin = t;
+						j.xout = yd;
+						launch_sweep(j, PART_NONE, POST_D_SUB, D_DBLOCKS, p->stream);
+						e.rhs = yd;
+						nl += 1 + exact_pass(p, e, PART_UPPER, POST_SUB_D, D_DBLOCKS, o, nullptr);
+					}
+					ph.launches = nl;
+				} else if (mode == BLASTED_HIP_LEVEL) {  // the same pass as one whole-row exact kernel
 					o = (cur == dx) ? other : dx;
 					ph.launches = exact_pass(p, a, PART_OFFDIAG, POST_D_SUB, D_DBLOCKS, o, cur);
 				} else {
@@ -1429,6 +1475,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
 		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)
 			set_factorodd_enabled(spec[10] != '0');
+		else if (spec && std::strncmp(spec, "relaxsplit=", 11) == 0)
+			g_relax_split = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)

@@ -216,6 +216,7 @@ static void dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, hi
 		return;                                                                                  \
 	}
 	BHIP_CASE(PART_LOWER, POST_SUB, D_NONE)
+	BHIP_CASE(PART_UPPER, POST_SUB, D_NONE)  // out = rhs - U x, strictly upper part (exact relaxation passes)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_VALS_DIAG)
 	BHIP_CASE(PART_UPPER, POST_D_SUB, D_RECIP_DIAG)
 	BHIP_CASE(PART_LOWER, POST_D_SUB, D_DBLOCKS)

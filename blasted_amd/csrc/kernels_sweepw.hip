@@ -417,6 +417,7 @@ static bool launch_bs(const SweepArgs &a, Part part, Post post, DSrc dsrc, const
 	if (part == P && post == Q && dsrc == D)                  \
 		ok = launch_variant<BS, P, Q, D>(a, v, s);
 	BHIP_CASEW(PART_LOWER, POST_SUB, D_NONE)
+	BHIP_CASEW(PART_UPPER, POST_SUB, D_NONE)
 	BHIP_CASEW(PART_UPPER, POST_D_SUB, D_VALS_DIAG)
 	BHIP_CASEW(PART_LOWER, POST_D_SUB, D_DBLOCKS)
 	BHIP_CASEW(PART_UPPER, POST_SUB_D, D_DBLOCKS)
