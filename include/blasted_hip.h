@@ -192,8 +192,10 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":
  * exact triangular solves read level-ordered copies of the factor's triangles (one extra copy of the
  * factor, permuted once per factorisation) or the factor in place (environment: BLASTED_HIP_LEVELSTORE);
- * "interleave=1": interleaved row order inside a chunk for the in-place sweeps (better sweep quality,
- * 14 % slower; default 0).
+ * "interleave=1": interleaved row order inside a chunk for the in-place sweeps (1.46x fewer sweeps for the
+ * same accuracy, 13-15 % slower per sweep; default 0; environment: BLASTED_HIP_INTERLEAVE).
+ * "relaxsplit=1" (default) / "relaxsplit=0": an exact relaxation pass runs as a product with the other
+ * triangle from the previous iterate plus an exact triangular solve, or as one whole-row exact kernel.
  * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
  * factor's triangles (one more copy of the factor, one copy pass per factorisation) or the factor in
  * place (environment: BLASTED_HIP_COMPACT).
