@@ -254,12 +254,14 @@ def main():
             try:
                 ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
                 st = p.level_stats()
+                sy = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC, out=z))
                 exf = _t(lambda: p.ilu0_factorize(-1), reps=2)
                 asf = _t(lambda: p.ilu0_factorize(args.build_sweeps), reps=2)
                 out["exact_apply"] = {"ms": ex, "levels": st["levels"], "syncfree_aborts": st["syncfree_aborts"],
-                                      "exact_factor_ms": exf, "async_factor_ms": asf,
-                                      "note": "one exact L and U solve (mode LEVEL), beside ms_per_step for %d+%d "
-                                              "asynchronous sweeps" % (s, s)}
+                                      "exact_factor_ms": exf, "async_factor_ms": asf, "sync_sweeps_ms": sy,
+                                      "note": "one exact L and U solve (mode LEVEL), and %d+%d SYNCHRONOUS sweeps "
+                                              "(deterministic; the first sweep from zero needs no matrix), beside "
+                                              "ms_per_step for %d+%d asynchronous sweeps" % (s, s, s, s)}
             except Exception as e:
                 out["exact_apply"] = {"ms": None, "note": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
