@@ -316,6 +316,8 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSrc dsrc, double *x,
                       const double *xold)
 {
+	if (p->pat.nbrows == 0)
+		return 0;  // an empty subdomain: nothing to solve
 	LevelSchedule &ls = need_levels(p);
 	if (g_level_impl == 0) {
 		LevelView view;

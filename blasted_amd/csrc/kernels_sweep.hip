@@ -252,6 +252,8 @@ bool sweep_offsets_fit(const Pattern &pat)
 
 void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
+	if (a.pat.nbrows == 0)
+		return;  // an empty subdomain
 	if (launch_sweepw(a, part, post, dsrc, s))
 		return;
 	if (launch_sweepodd(a, part, post, dsrc, s))

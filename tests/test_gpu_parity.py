@@ -112,6 +112,31 @@ def test_invalid_patterns_are_rejected():
     assert ei.value.code == capi.ENOTIMPL
 
 
+@pytest.mark.parametrize("bs", [1, 4, 5])
+def test_empty_subdomain_is_a_no_op(bs):
+    """A rank whose subdomain has no rows (nbrows = 0): every operator succeeds and returns empty vectors."""
+    m = dict(nbrows=0, nnzb=0, bs=bs, rowmajor=False, browptr=np.zeros(1, np.int32),
+             bcolind=np.zeros(0, np.int32), diagind=np.zeros(0, np.int32), vals=np.zeros(0))
+    p = capi.Prec(0)
+    p.set_matrix(m)
+    r = np.zeros(0)
+    p.ilu0_factorize(3)
+    p.ilu0_factorize(-1)
+    assert p.ilu0_apply(r, 3).shape == (0,)
+    assert p.ilu0_apply(r, 1, mode=capi.LEVEL).shape == (0,)
+    assert p.ilu0_apply(r, 2, mode=capi.JACOBI_SYNC).shape == (0,)
+    p.jacobi_compute()
+    assert p.jacobi_apply(r).shape == (0,)
+    assert p.sgs_apply(r, 2).shape == (0,)
+    assert p.sgs_apply(r, 1, mode=capi.LEVEL).shape == (0,)
+    p.sgs_relax(r, np.zeros(0), 2)
+    p.sgs_relax(r, np.zeros(0), 1, mode=capi.LEVEL)
+    p.gs_relax(r, np.zeros(0), 2)
+    assert p.spmv(r).shape == (0,)
+    assert p.level_count() == 0
+    p.close()
+
+
 def test_measure_read_stream_reports_a_plausible_rate():
     """The measurement aid behind bench.py's roofline.measured_read_stream_gbps: a 256 MB buffer streams at
     well above 1 TB/s and below the 8 TB/s peak; misaligned and null buffers are rejected."""
