@@ -541,7 +541,8 @@ int blasted_hip_set_pattern(blasted_hip_prec p, int nbrows, int nnzb, int bs, in
 		check_loc(loc);
 		if (p->have_pattern)
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "the sparsity pattern of an operator is set once");
-		if (nbrows < 0 || nnzb < 0 || !browptr || !bcolind || !diagind)
+		// (an empty subdomain may come with null bcolind / diagind: there is nothing behind them)
+		if (nbrows < 0 || nnzb < 0 || !browptr || (nnzb > 0 && !bcolind) || (nbrows > 0 && !diagind))
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "set_pattern: null array or negative size");
 		if (layout != BLASTED_HIP_COLMAJOR && layout != BLASTED_HIP_ROWMAJOR)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "Block ordering must be either rowmajor or colmajor!");
@@ -604,9 +605,9 @@ int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
 		use_device(p);
 		check_loc(loc);
 		need_pattern(p);
-		if (!vals)
+		if (!vals && p->nvals() > 0)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "set_values: null array");
-		if (loc == BLASTED_HIP_DEVICE) {
+		if (loc == BLASTED_HIP_DEVICE && vals) {
 			p->vals = vals;
 		} else {
 			if (!p->vals_own)

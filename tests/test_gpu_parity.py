@@ -135,6 +135,16 @@ def test_empty_subdomain_is_a_no_op(bs):
     assert p.spmv(r).shape == (0,)
     assert p.level_count() == 0
     p.close()
+    # the same through the raw ABI with the null pointers an empty std::vector hands over
+    import ctypes as C
+    h = C.c_void_p(0)
+    L = capi.lib()
+    assert L.blasted_hip_create(C.byref(h), 0, None, 1) == 0
+    rp = np.zeros(1, np.int32)
+    assert L.blasted_hip_set_pattern(h, 0, 0, bs, 0, rp.ctypes.data_as(C.c_void_p), None, None, capi.HOST) == 0
+    assert L.blasted_hip_set_values(h, None, capi.HOST) == 0
+    assert L.blasted_hip_ilu0_factorize(h, 3, capi.INIT_F_ORIGINAL, 0, capi.ASYNC, None) == 0
+    L.blasted_hip_destroy(h)
 
 
 def test_measure_read_stream_reports_a_plausible_rate():
