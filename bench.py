@@ -1,19 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its config[1]:
+"""bench.py -- BASELINE.json's metric (precond-apply sweeps/s + achieved HBM GB/s) on its configs.
+
+Default (= --config 2, BASELINE.json configs[1], the configuration the metric is quoted on):
   async block-ILU(0) apply, BSR bs=4, 3-D Poisson 256^3 (16.7 M block-rows, 15 GB of factor), 1 GPU.
 
-A "step" is one preconditioner application z = U^-1 L^-1 r through the C ABI
-(blasted_hip_ilu0_apply, device pointers): y := 0, `s` asynchronous lower sweeps, z := 0, `s`
-asynchronous upper sweeps (s = --sweeps, default 3 as in the reference's calibration runs).
-value = L+U sweep pairs per second over the whole job (all ranks); every input is resident in HBM
-before the timed region.  Multi-GPU = independent replicas (the operator is the subdomain-local
-preconditioner: the matrix is replicated per GPU, there is no data-path collective).
+A "step" is one application of the operator through the C ABI with device pointers; for the ILU apply:
+y := 0, `s` asynchronous lower sweeps, z := 0, `s` asynchronous upper sweeps (s = 3 as in the reference's
+calibration runs).  value = sweeps (L+U pairs, or relaxation steps) per second over the whole job (all
+ranks); every input is resident in HBM before the timed region.  Multi-GPU = independent replicas (the
+operator is the subdomain-local preconditioner: the matrix is replicated per GPU, no data-path collective).
 
-python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--sweeps 3] [--op ilu_apply]
+--config K selects the other BASELINE.json configurations (numbered 1..5 in the order of its `configs`):
+  1  Poisson 64^3 scalar CSR (Chebyshev grid, the reference's own test problem), async ILU(0), 3 sweeps
+  2  Poisson 256^3 bs=4, async block-ILU(0) apply (+ factor timing beside it)           [default]
+  3  Poisson 256^3 bs=4, async block-SGS relaxation, 5 steps
+  4  unstructured bs=5, 126^3 = 2.0 M block-rows (workloads.unstructured_bsr), async block-ILU(0)
+  5  Poisson 100^3 pattern bs=8 (1.0 M block-rows), block-ILU(0) apply
+Each prints the same JSON line with its own `roofline` (dominant kernel, HIP-event time inside the timed
+region, algorithmic bytes from the actual pattern counts) and `cpu_baseline`.
+
+python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1..5] [--n 256] [--bs 4] [--sweeps 3] [--op ilu_apply]
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N replica processes itself, one per GPU, before
+anything in this process touches the GPU; under torchrun (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,29 +37,65 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+CONFIGS = {
+    1: dict(workload="poisson3d_64_csr_async_ilu0_apply", gen="poisson", n=64, bs=1, grid="chebyshev",
+            op="ilu_apply", sweeps=3, build=3, cpu_n=64),
+    2: dict(workload="poisson3d_256_bs4_async_block_ilu0_apply", gen="poisson", n=256, bs=4, grid="uniform",
+            op="ilu_apply", sweeps=3, build=3, cpu_n=96),
+    3: dict(workload="poisson3d_256_bs4_async_block_sgs_relaxation", gen="poisson", n=256, bs=4, grid="uniform",
+            op="sgs_relax", sweeps=5, build=3, cpu_n=96),
+    4: dict(workload="unstructured_126_bs5_async_block_ilu0_apply", gen="unstructured", n=126, bs=5, grid="-",
+            op="ilu_apply", sweeps=3, build=3, cpu_n=40),
+    5: dict(workload="poisson3d_100_bs8_block_ilu0_apply", gen="poisson", n=100, bs=8, grid="uniform",
+            op="ilu_apply", sweeps=3, build=3, cpu_n=56),
+}
 
-def algorithmic_bytes(n, bs):
-    """compulsory bytes, every array touched once per sweep."""
-    nb = n ** 3
-    nnzb = 7 * n ** 3 - 6 * n ** 2
-    nnzl = 3 * n ** 3 - 3 * n ** 2
+
+def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs):
+    """compulsory bytes, every array touched once per sweep, from the pattern's counts."""
     B, S, I = 8 * bs * bs, 8 * bs, 4
     lower = nnzl * (B + I) + 2 * nb * I + 3 * nb * S
-    upper = (nnzl + nb) * B + nnzl * I + 2 * nb * I + 3 * nb * S
+    upper = (nnzu + nb) * B + nnzu * I + 2 * nb * I + 3 * nb * S
     return {
         "lower_sweep": lower, "upper_sweep": upper, "ilu_pair": lower + upper,
-        "sgs_pair": 2 * nnzl * (B + I) + 2 * nb * B + 4 * nb * I + 6 * nb * S,
-        "sgs_relax_pass": 2 * nnzl * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
-        "factor_sweep": 3 * nnzb * B + 2 * nnzb * I + 2 * nb * I + 2 * nnzl * I,
+        "sgs_pair": (nnzl + nnzu) * (B + I) + 2 * nb * B + 4 * nb * I + 6 * nb * S,
+        "sgs_bwd": nnzu * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
+        "sgs_relax_pass": (nnzl + nnzu) * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
+        "factor_sweep": 3 * nnzb * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
         "spmv": nnzb * (B + I) + (nb + 1) * I + 2 * nb * S,
-        "nbrows": nb, "nnzb": nnzb,
+        "nbrows": nb, "nnzb": nnzb, "nnzl": nnzl, "nnzu": nnzu, "pairs": npairs,
     }
 
 
-def cpu_baseline(op, nsample, bs, sweeps, full_unit_bytes, units_per_call, budget_s=12.0):
+def algorithmic_bytes(n, bs):
+    """The N^3 7-point pattern (every bench config but the unstructured one)."""
+    nb = n ** 3
+    nnzb = 7 * n ** 3 - 6 * n ** 2
+    nnzl = 3 * n ** 3 - 3 * n ** 2
+    return pattern_bytes(nb, nnzb, nnzl, nnzl, nnzl, bs)
+
+
+def matrix_counts(m):
+    """(nb, nnzb, nnzL, nnzU) of a matrix dict of numpy arrays or torch tensors."""
+    nb, nnzb = int(m["nbrows"]), int(m["nnzb"])
+    rp, dg = m["browptr"], m["diagind"]
+    nnzl = int((dg.long() - rp[:-1].long()).sum().item()) if hasattr(dg, "long") else int((dg.astype("int64") - rp[:-1]).sum())
+    return nb, nnzb, nnzl, nnzb - nb - nnzl
+
+
+def unit_of(op, ab):
+    """(bytes of one unit of `value`, bytes of one launch of the dominant kernel, which timing bucket it is in)"""
+    return {"ilu_apply": (ab["ilu_pair"], ab["upper_sweep"], "upper"),
+            "sgs_apply": (ab["sgs_pair"], ab["sgs_bwd"], "upper"),
+            "sgs_relax": (2 * ab["sgs_relax_pass"], ab["sgs_relax_pass"], "upper"),
+            "spmv": (ab["spmv"], ab["spmv"], "lower"),
+            "factor": (ab["factor_sweep"], ab["factor_sweep"], "lower")}[op]
+
+
+def cpu_baseline(cfg, op, sweeps, full_unit_bytes, units_per_call, budget_s=12.0):
     """The oracle's threaded port of the reference loop nest (omp for schedule(dynamic,256) nowait),
-    timed on this box's host cores on a bounded sample of the same workload (nsample^3 instead of
-    256^3), scaled to the metric's unit by algorithmic bytes."""
+    timed on this box's host cores on a bounded sample of the same workload (a smaller grid of the same
+    generator), scaled to the metric's unit by algorithmic bytes."""
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     import oracle
@@ -53,29 +104,35 @@ def cpu_baseline(op, nsample, bs, sweeps, full_unit_bytes, units_per_call, budge
     # threads than that only thrash; the count is what `cores` reports
     budget = oracle.cpu_budget()
     oracle.set_num_threads(budget)
-    m = workloads.poisson3d(nsample + 2, bs, grid="uniform")
+    nsample, bs = cfg["cpu_n"], cfg["bs"]
+    if cfg["gen"] == "unstructured":
+        m = workloads.to_numpy(workloads.unstructured_bsr(nsample, bs, device="cpu"))
+        what = "unstructured %d^3" % nsample
+    else:
+        m = workloads.poisson3d(nsample + 2, bs, grid=cfg["grid"])
+        what = "Poisson %d^3 (%s grid)" % (nsample, cfg["grid"])
     r = workloads.rhs_vector(m["nbrows"] * bs)
     kw = {}
+    plist = oracle.ilu_positions(m)
     if op == "ilu_apply":
-        kw["iluvals"] = oracle.ilu0_factorize(m, None, 1, mode=oracle.GS_SERIAL)["iluvals"]
+        kw["iluvals"] = oracle.ilu0_factorize(m, plist, 1, mode=oracle.GS_SERIAL)["iluvals"]
     elif op == "factor":
-        kw["plist"] = oracle.ilu_positions(m)
+        kw["plist"] = plist
     elif op != "spmv":
         kw["dblocks"] = oracle.jacobi_compute(m)
     t1 = oracle.time_op(op, m, r, sweeps, 256, 2, **kw)
     reps = max(3, min(200, int(budget_s / max(t1, 1e-4))))
     t = oracle.time_op(op, m, r, sweeps, 256, reps, **kw)
-    ab = algorithmic_bytes(nsample, bs)
-    sample_unit = {"ilu_apply": ab["ilu_pair"], "sgs_apply": ab["sgs_pair"], "sgs_relax": 2 * ab["sgs_relax_pass"],
-                   "spmv": ab["spmv"], "factor": ab["factor_sweep"]}[op]
+    nb, nnzb, nnzl, nnzu = matrix_counts(m)
+    sample_unit = unit_of(op, pattern_bytes(nb, nnzb, nnzl, nnzu, int(plist[1].size), bs))[0]
     return {
         "value": (units_per_call / t) * sample_unit / full_unit_bytes,
         "unit": "sweeps/s", "cores": oracle.num_threads(), "kind": "port",
         "achieved_gbps": sample_unit * units_per_call / t / 1e9,
-        "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) %s on Poisson %d^3 bs=%d, %d sweeps per call, "
+        "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) %s on %s bs=%d, %d sweeps per call, "
                   "min of %d calls = %.1f ms, %d OpenMP threads = the CPUs granted to this process (%d hardware "
                   "threads visible); scaled to the full size by algorithmic bytes" %
-                  (op, nsample, bs, sweeps, reps, t * 1e3, oracle.num_threads(), os.cpu_count() or 0),
+                  (op, what, bs, sweeps, reps, t * 1e3, oracle.num_threads(), os.cpu_count() or 0),
     }
 
 
@@ -111,167 +168,286 @@ def measured_copy_gbps(dev, nbytes=1 << 31, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_replicas(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the
+    rendezvous variables torchrun would set.  Runs before this process has made any HIP / torch.cuda call
+    (a process that has initialised the GPU must never be replaced or forked on this pool); the parent only
+    waits, forwards rank 0's JSON line and returns the worst exit code."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for rank in range(ngpus):
+        env = dict(os.environ, WORLD_SIZE=str(ngpus), RANK=str(rank), LOCAL_RANK=str(rank),
+                   LOCAL_WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    text = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        rc = pr.wait() or rc
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return rc
+
+
+def quality_figures(p, capi, torch, r, z, s):
+    """Side figure, never `value`: what the s+s asynchronous sweeps are worth as a preconditioner -- the
+    relative distance of z to the exact triangular solves after s+s and 10+10 sweeps, the contraction per
+    sweep between them, and from it the sweeps (and milliseconds) to reach 1e-2 and 1e-6."""
+    import math
+    ze = p.ilu0_apply(r, 1, mode=capi.LEVEL, out=torch.empty_like(z)).clone()
+    nz = float(torch.linalg.vector_norm(ze))
+
+    def dist_after(k):
+        p.ilu0_apply(r, k, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
+        return float(torch.linalg.vector_norm(z - ze)) / nz
+
+    def ms_of(k, reps=3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            p.ilu0_apply(r, k, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+    d_s, d_10 = dist_after(s), dist_after(10)
+    out = {"distance_after_%d+%d" % (s, s): d_s, "distance_after_10+10": d_10}
+    if 0 < d_10 < d_s and s < 10:
+        rho = (d_10 / d_s) ** (1.0 / (10 - s))
+        per = ms_of(s) / s
+        out["contraction_per_sweep"] = rho
+        for tol, key in ((1e-2, "1e-2"), (1e-6, "1e-6")):
+            k = max(s, s + math.ceil(math.log(tol / d_s) / math.log(rho)))
+            out["sweeps_to_" + key] = k
+            out["ms_to_" + key] = k * per
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=256, help="grid points per axis (256 = BASELINE config)")
-    ap.add_argument("--bs", type=int, default=4)
-    ap.add_argument("--sweeps", type=int, default=3, help="napplysweeps")
-    ap.add_argument("--build-sweeps", type=int, default=3)
-    ap.add_argument("--op", default="ilu_apply", choices=["ilu_apply", "sgs_apply", "sgs_relax", "spmv", "factor"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration, numbered 1..5 (2 = the one the metric is quoted on)")
+    ap.add_argument("--n", type=int, default=None, help="grid points per axis (overrides the config's)")
+    ap.add_argument("--bs", type=int, default=None)
+    ap.add_argument("--sweeps", type=int, default=None, help="napplysweeps / relaxation steps")
+    ap.add_argument("--build-sweeps", type=int, default=None)
+    ap.add_argument("--op", default=None, choices=["ilu_apply", "sgs_apply", "sgs_relax", "spmv", "factor"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=96)
+    ap.add_argument("--cpu-sample-n", type=int, default=None)
     args = ap.parse_args()
+
+    dry = os.environ.get("BLASTED_BENCH_DRYRUN") == "1"  # tests of the launcher: gloo, no GPU, no kernels
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_replicas(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE=%s" %
+                         (args.gpus, os.environ["WORLD_SIZE"]))
+
+    cfg = dict(CONFIGS[args.config])
+    custom = False
+    for key, val in (("n", args.n), ("bs", args.bs), ("sweeps", args.sweeps), ("build", args.build_sweeps),
+                     ("op", args.op), ("cpu_n", args.cpu_sample_n)):
+        if val is not None and val != cfg[key]:
+            cfg[key] = val
+            custom = custom or key != "cpu_n"
+    n, bs, s, op = cfg["n"], cfg["bs"], cfg["sweeps"], cfg["op"]
+    if custom:
+        kind = {"ilu_apply": "async_ilu0_apply", "sgs_apply": "async_sgs_apply", "sgs_relax": "async_sgs_relaxation",
+                "spmv": "spmv", "factor": "async_ilu0_factor"}[op]
+        cfg["workload"] = "%s_%d_bs%d_%s" % ("unstructured" if cfg["gen"] == "unstructured" else "poisson3d", n, bs, kind)
 
     import torch
     import torch.distributed as dist
-    from blasted_amd import capi, workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    n, bs, s = args.n, args.bs, args.sweeps
-    ab = algorithmic_bytes(n, bs)
-
-    # ---- workload resident in HBM
-    m = workloads.poisson3d_device(n, bs, dev, grid="uniform")
-    r = workloads.rhs_vector_device(m["nbrows"] * bs, dev)
-    z = torch.zeros_like(r)
-    torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
-    p = capi.Prec(local_rank, stream)
-    p.set_matrix(m)
-
-    if args.op in ("ilu_apply", "factor"):
-        p.ilu0_factorize(args.build_sweeps, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+    if dry:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        dev = torch.device("cpu")
+        sync = lambda: None
     else:
-        p.jacobi_compute()
-    torch.cuda.synchronize()
-
-    if args.op == "ilu_apply":
-        step = lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
-        unit_bytes, units_per_step, kernel, kbytes = ab["ilu_pair"], s, "upper", ab["upper_sweep"]
-        workload = "poisson3d_%d_bs%d_async_block_ilu0_apply" % (n, bs)
-    elif args.op == "sgs_apply":
-        step = lambda: p.sgs_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
-        unit_bytes, units_per_step, kernel, kbytes = ab["sgs_pair"], s, "upper", ab["sgs_pair"] / 2
-        workload = "poisson3d_%d_bs%d_async_block_sgs_apply" % (n, bs)
-    elif args.op == "sgs_relax":
-        step = lambda: p.sgs_relax(r, z, s, mode=capi.ASYNC)
-        unit_bytes, units_per_step, kernel, kbytes = 2 * ab["sgs_relax_pass"], s, "upper", ab["sgs_relax_pass"]
-        workload = "poisson3d_%d_bs%d_async_block_sgs_relaxation" % (n, bs)
-    elif args.op == "spmv":
-        step = lambda: p.spmv(r, out=z)
-        unit_bytes, units_per_step, kernel, kbytes = ab["spmv"], 1, "lower", ab["spmv"]
-        workload = "poisson3d_%d_bs%d_bsr_spmv" % (n, bs)
-    else:
-        step = lambda: p.ilu0_factorize(s, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
-        unit_bytes, units_per_step, kernel, kbytes = ab["factor_sweep"], s, "lower", ab["factor_sweep"]
-        workload = "poisson3d_%d_bs%d_async_block_ilu0_factor" % (n, bs)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    p = None
+    if dry:
+        ab = algorithmic_bytes(n, bs)
+        step = lambda: time.sleep(0.002)
+    else:
+        from blasted_amd import capi, workloads
+        # ---- workload resident in HBM
+        if cfg["gen"] == "unstructured":
+            m = workloads.unstructured_bsr(n, bs, device=dev)
+        else:
+            m = workloads.poisson3d_device(n, bs, dev, grid=cfg["grid"])
+        r = workloads.rhs_vector_device(m["nbrows"] * bs, dev)
+        z = torch.zeros_like(r)
+        sync()
+        stream = torch.cuda.current_stream().cuda_stream
+        p = capi.Prec(local_rank, stream)
+        p.set_matrix(m)
+        nb, nnzb, nnzl, nnzu = matrix_counts(m)
+        npairs = nnzl
+        if op in ("ilu_apply", "factor"):
+            p.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+            npairs = p.ilu0_positions_size()
+        else:
+            p.jacobi_compute()
+        ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs)
+        sync()
+        step = {
+            "ilu_apply": lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z),
+            "sgs_apply": lambda: p.sgs_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z),
+            "sgs_relax": lambda: p.sgs_relax(r, z, s, mode=capi.ASYNC),
+            "spmv": lambda: p.spmv(r, out=z),
+            "factor": lambda: p.ilu0_factorize(s, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC),
+        }[op]
+    unit_bytes, kbytes, kernel = unit_of(op, ab)
+    units_per_step = 1 if op == "spmv" else s
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    p.set_timing(True)
-    p.get_timing(reset=True)
+    sync()
+    if p:
+        p.set_timing(True)
+        p.get_timing(reset=True)
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     barrier()
     t1 = time.perf_counter()
-    tm = p.get_timing(reset=True)
-    p.set_timing(False)
+    tm = None
+    if p:
+        tm = p.get_timing(reset=True)
+        p.set_timing(False)
 
     elapsed = max_over_ranks(t1 - t0, dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = job_throughput(world, units_per_step, args.steps, elapsed)
-        copy_gbps = measured_copy_gbps(dev)
-        # practical read ceiling of this device: the matrix's own value array through a read-only kernel
-        read_gbps = capi.measure_read_stream(m["vals"], reps=10)
-        kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
-        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.op, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "precond_apply_sweeps_per_sec", "value": value, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": workload, "grid_points": n, "block_size": bs, "nbrows": ab["nbrows"],
-                       "nnzb": ab["nnzb"], "napplysweeps": s, "nbuildsweeps": args.build_sweeps,
-                       "sweep_mode": "async", "grid": "uniform", "replicas": world,
-                       "unit_definition": "one L+U sweep pair = %d algorithmic bytes" % unit_bytes},
-            "achieved_gbps": unit_bytes * units_per_step / (ms_per_step * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "measured_read_stream_gbps": read_gbps, "frac_of_read_stream": achieved / read_gbps,
-                         "kernel": "%s (%s pass; bhip::sweepw_kernel<%d, ...> in the rocprofv3 summaries)" % (
-                             {"ilu_apply": "upper triangular sweep z <- D^-1 (y - U z)",
-                              "sgs_apply": "backward Gauss-Seidel sweep z <- y - D^-1 U z",
-                              "sgs_relax": "relaxation pass x <- D^-1 (b - (A - D) x)", "spmv": "BSR SpMV",
-                              "factor": "ILU(0) fixed-point sweep (bhip::factor4_kernel)"}[args.op],
-                             "descending" if kernel == "upper" else "ascending", bs),
-                         "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes,
-                         "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
-                         "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
-                         "other_ms_per_step": tm["other_ms"] / args.steps},
+            "data": "dry-run (launcher test: no kernels ran)" if dry else "synthetic",
+            "config": {"workload": cfg["workload"], "baseline_config": None if custom else args.config,
+                       "generator": cfg["gen"], "grid_points": n, "block_size": bs, "nbrows": ab["nbrows"],
+                       "nnzb": ab["nnzb"], "nnz_lower": ab["nnzl"], "nnz_upper": ab["nnzu"],
+                       "napplysweeps": s, "nbuildsweeps": cfg["build"], "sweep_mode": "async", "grid": cfg["grid"],
+                       "replicas": world,
+                       "unit_definition": "one %s = %d algorithmic bytes" % (
+                           {"ilu_apply": "L+U sweep pair", "sgs_apply": "forward+backward sweep pair",
+                            "sgs_relax": "relaxation step (ascending + descending pass)", "spmv": "product",
+                            "factor": "factorisation sweep"}[op], unit_bytes)},
+            "achieved_gbps": unit_bytes * units_per_step * world / (ms_per_step * 1e-3) / 1e9,
         }
-        if world == 1 and args.op == "ilu_apply":
-            # side figure, never `value`: the exact (level-scheduled) solve the sweeps approximate
-            def _t(fn, reps=5):
+        if not dry:
+            copy_gbps = measured_copy_gbps(dev)
+            # practical read ceiling of this device: the matrix's own value array through a read-only kernel
+            read_gbps = capi.measure_read_stream(m["vals"], reps=10)
+            kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
+            achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    tj = json.load(open(tf))
+                    ent = tj.get(cfg["workload"]) or (tj.get(op) if args.config == 2 and not custom else None) or {}
+                    traffic = ent.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            family = ("sweepw_kernel<%d, ...>" % bs if bs in (4, 8) else
+                      "sweepodd_kernel<%d, ...>" % bs if bs in (3, 5, 7) else "sweep_kernel<%d, ...>" % bs)
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                "measured_read_stream_gbps": read_gbps, "frac_of_read_stream": achieved / read_gbps,
+                "kernel": "%s (%s pass; bhip::%s in the rocprofv3 summaries)" % (
+                    {"ilu_apply": "upper triangular sweep z <- D^-1 (y - U z)",
+                     "sgs_apply": "backward Gauss-Seidel sweep z <- y - D^-1 U z",
+                     "sgs_relax": "relaxation pass x <- D^-1 (b - (A - D) x)", "spmv": "BSR SpMV",
+                     "factor": "ILU(0) fixed-point sweep"}[op],
+                    "descending" if kernel == "upper" else "ascending",
+                    "factor kernel" if op == "factor" else family),
+                "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes,
+                "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
+                "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
+                "other_ms_per_step": tm["other_ms"] / args.steps}
+
+        def _t(fn, reps=5):
+            fn()
+            sync()
+            t = time.perf_counter()
+            for _ in range(reps):
                 fn()
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / reps * 1e3
+            sync()
+            return (time.perf_counter() - t) / reps * 1e3
+        if not dry and world == 1 and op == "ilu_apply":
+            # side figures, never `value`: the factorisation next to the apply, the exact (level-scheduled)
+            # solve the sweeps approximate, and what the sweeps are worth as a preconditioner
             try:
+                p.set_timing(True)
+                p.get_timing(reset=True)
+                asf = _t(lambda: p.ilu0_factorize(cfg["build"]), reps=2)
+                tf_ = p.get_timing(reset=True)
+                p.set_timing(False)
+                fms = tf_["lower_ms"] / max(tf_["lower_launches"], 1)
+                out["factor"] = {"async_factor_ms": asf, "nbuildsweeps": cfg["build"], "sweep_ms": fms,
+                                 "algorithmic_bytes_per_sweep": ab["factor_sweep"],
+                                 "achieved": ab["factor_sweep"] / (fms * 1e-3) / 1e9 if fms > 0 else 0.0,
+                                 "frac": ab["factor_sweep"] / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else 0.0}
                 ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
                 st = p.level_stats()
                 sy = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC, out=z))
-                exf = _t(lambda: p.ilu0_factorize(-1), reps=2)
-                asf = _t(lambda: p.ilu0_factorize(args.build_sweeps), reps=2)
                 out["exact_apply"] = {"ms": ex, "levels": st["levels"], "syncfree_aborts": st["syncfree_aborts"],
-                                      "exact_factor_ms": exf, "async_factor_ms": asf, "sync_sweeps_ms": sy,
+                                      "sync_sweeps_ms": sy,
                                       "note": "one exact L and U solve (mode LEVEL), and %d+%d SYNCHRONOUS sweeps "
                                               "(deterministic; the first sweep from zero needs no matrix), beside "
                                               "ms_per_step for %d+%d asynchronous sweeps" % (s, s, s, s)}
+                out["quality"] = quality_figures(p, capi, torch, r, z, s)
+                exf = _t(lambda: p.ilu0_factorize(-1), reps=2)
+                out["exact_apply"]["exact_factor_ms"] = exf
             except Exception as e:
                 out["exact_apply"] = {"ms": None, "note": "failed: %r" % (e,)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not dry and world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.op, args.cpu_sample_n, bs, s, unit_bytes, units_per_step)
+                out["cpu_baseline"] = cpu_baseline(cfg, op, s, unit_bytes, units_per_step)
             except Exception as e:  # the baseline is a reported side figure, never the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
-    p.close()
+    if p:
+        p.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -190,6 +190,12 @@ class Prec:
         _check(lib().blasted_hip_ilu0_get_positions(self._h, _ptr(posptr), _ptr(lowerp), _ptr(upperp)))
         return posptr, lowerp, upperp
 
+    def ilu0_positions_size(self):
+        """Number of (lower, upper) position pairs (after ilu0_positions / ilu0_factorize)."""
+        n = C.c_long(0)
+        _check(lib().blasted_hip_ilu0_positions_size(self._h, C.byref(n)))
+        return int(n.value)
+
     def ilu0_factorize(self, nbuildsweeps, init=INIT_F_ORIGINAL, usescale=False, mode=ASYNC,
                        compute_info=False):
         info = np.zeros(6) if compute_info else None

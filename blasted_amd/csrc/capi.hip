@@ -291,7 +291,7 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 	a.vals = view.vals;
 	a.xin = out;
 	a.xout = out;
-	a.xnat = upper ? x : nullptr;
+	a.xnat = (upper || p->y_natural_too) ? x : nullptr;
 	if (upper)
 		a.rhs = p->yperm;
 	if (!launch_syncfree_wide(a, upper, ls, view.ptr, view.colp, view.headp, p->stream, true, sgs))
@@ -307,7 +307,7 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 		return 0;
 	}
 	if (!upper)
-		p->y_in_level_order = true;
+		p->y_in_level_order = !p->y_natural_too;  // (with the second output ytemp is current as well)
 	return 2;
 }
 
@@ -385,6 +385,10 @@ static int g_interleave = [] {
 // tuning ("relaxsplit=0|1"): exact relaxation passes as product + exact triangular solve (default) or as one
 // whole-row exact kernel
 static int g_relax_split = 1;
+
+// tuning ("sgsfwd=exact|async"): the forward half of an ASYNC-mode SGS application as one exact in-order pass (the
+// reference's semantics, default) or as napplysweeps asynchronous sweeps
+static int g_sgs_exact_fwd = 1;
 
 static SweepArgs base_args(blasted_hip_prec p)
 {
@@ -1017,6 +1021,46 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		}
 		const bool reinit = apply_init == BLASTED_HIP_INIT_A_JACOBI || apply_init == BLASTED_HIP_INIT_A_ZERO;
 		p->y_in_level_order = false;  // this call rewrites ytemp
+		// The reference's forward loop stands OUTSIDE any parallel region (src/solverops_sgs.cpp:62-66 calls
+		// perform_block_fgs, whose `omp for` is then orphaned, src/kernels/kernels_sgs.hpp:127): whatever the
+		// thread and sweep counts, y = (D+L)^-1 r is the exact serial solve and only the backward sweeps are
+		// asynchronous.  The product mode does the same: ONE exact in-order forward pass (repeating it changes
+		// nothing, and it does not read the initial ytemp), then napplysweeps asynchronous backward sweeps.
+		// "sgsfwd=async" restores napplysweeps asynchronous forward sweeps (round 1's form, a tuning variant).
+		if (mode == BLASTED_HIP_ASYNC && g_sgs_exact_fwd && napplysweeps >= 1 && p->pat.nbrows > 0) {
+			SweepArgs f = base_args(p);
+			f.vals = p->vals;
+			f.dvals = p->dblocks;
+			f.rhs = dr;
+			f.descending = 0;
+			{
+				Phase ph(p, 0);
+				p->y_natural_too = true;  // the backward sweeps read y by row
+				ph.launches = exact_pass(p, f, PART_LOWER, POST_D_SUB, D_DBLOCKS, p->ytemp, nullptr);
+				p->y_natural_too = false;
+				restore_ytemp(p);
+				ph.done();
+			}
+			SweepArgs a = base_args(p);
+			a.vals = p->vals;
+			a.dvals = p->dblocks;
+			a.rhs = p->ytemp;
+			a.descending = 1;
+			if (g_compact)
+				compact_args(p, true, a, p->vals, p->mat_nat);
+			const double *first_in = nullptr;
+			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
+				first_in = p->ytemp;  // z0 = y: the first sweep gathers from y
+			else if (apply_init == BLASTED_HIP_INIT_A_ZERO) {
+				Phase ph(p, 2);
+				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
+				ph.launches = 1;
+				ph.done();
+			}
+			run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, nullptr, first_in, napplysweeps, mode, 1);
+			finish_out(p, z, dz, loc);
+			return;
+		}
 		// Synchronous sweeps from a zero iterate need no matrix for their first sweep (as in ilu0_apply): the
 		// forward one is y1 = D^-1 r, the backward one z1 = y -- bit-identical, the skipped products are with zeros.
 		const bool skip_fwd = jac && reinit && napplysweeps >= 1;
@@ -1480,6 +1524,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_factorodd_enabled(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "relaxsplit=", 11) == 0)
 			g_relax_split = spec[11] != '0';
+		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
+			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)

@@ -242,6 +242,7 @@ struct blasted_hip_prec_s {
 	};
 	double *yperm = nullptr, *zperm = nullptr;  // level-ordered iterates of the exact ILU solves
 	bool y_in_level_order = false;              // yperm holds L^-1 r of the last exact apply, ytemp is stale
+	bool y_natural_too = false;                 // the next exact lower solve also writes y by row (into its x)
 	bhip::LevelSchedule natstore;  // natural-order compact triangle storage (pattern part)
 	TriCopy fac_nat, fac_lvl, mat_nat, mat_lvl;
 

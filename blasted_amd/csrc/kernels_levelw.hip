@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 					char *const dst = obase + (osel * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
 					sfw_store(dst, o0);
 					sfw_store(dst + 8, o1);
-					if (PERM && UPPER && a.xnat) {
+					if (PERM && a.xnat) {
 						double2_t o2;
 						o2.x = o0;
 						o2.y = o1;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int
 			}
 			if (!done && gready && t < BS) {
 				sfw_store(obase + ((unsigned)(PERM ? p : row) * (unsigned)ROWBYTES + 8u * (unsigned)t), out);
-				if (PERM && UPPER && a.xnat)
+				if (PERM && a.xnat)
 					a.xnat[(long)row * BS + t] = out;
 			}
 			done = done || gready;

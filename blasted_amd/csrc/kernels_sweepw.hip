@@ -68,7 +68,22 @@ struct WGeo {
 	static constexpr int ROWBYTES = BS * 8;
 };
 
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV>
+// SC: the iterate is gathered and stored with relaxed AGENT-scope accesses (sc1: coherent across the eight
+// per-XCD L2s) instead of plain ones -- the experiment SURVEY section 7 asks for ("without agent scope a sweep
+// degrades to per-XCD Jacobi"); the matrix stream stays non-temporal.  Tuning string "...,c1".
+__device__ __forceinline__ double sc_load(const char *p)
+{
+	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+	                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ void sc_store(char *p, const double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
 	using Ge = WGeo<BS, NBV>;
@@ -185,8 +200,12 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 					if (PART != PART_NONE && jj < jend[u] && !skip) {
 						const int cidx = jj - jlo;
 						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-						xg[u][kg] = *reinterpret_cast<const double2_t *>(
-						    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q >> 2)));
+						const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q >> 2));
+						if (SC) {
+							xg[u][kg].x = sc_load(xp);
+							xg[u][kg].y = sc_load(xp + 8);
+						} else
+							xg[u][kg] = *reinterpret_cast<const double2_t *>(xp);
 					}
 				}
 			}
@@ -214,8 +233,8 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 #else
 						const int cidx = jj - jlo;
 						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-						xv[u][k] = *reinterpret_cast<const double *>(
-						    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+						const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
+						xv[u][k] = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
 #endif
 					}
 				}
@@ -270,8 +289,8 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
 					const int cidx = jj - jlo;
 					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					const double xc = *reinterpret_cast<const double *>(
-					    xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c));
+					const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
+					const double xc = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
 					acc0 += v2.x * xc;
 					acc1 += v2.y * xc;
 				}
@@ -325,9 +344,12 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				double2_t o2;
 				o2.x = o0;
 				o2.y = o1;
-				double2_t *const dst = reinterpret_cast<double2_t *>(
-				    obase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q));
-				*dst = o2;
+				char *const dst = obase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)q);
+				if (SC) {
+					sc_store(dst, o0);
+					sc_store(dst + 8, o1);
+				} else
+					*reinterpret_cast<double2_t *>(dst) = o2;
 			}
 		}
 	}
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 
 struct Variant {
 	int rchunk = 128, nt = 1, unr = 1, enabled = 1;
+	int sc = 0;   // 1: agent-scope gathers and stores of the iterate (bs=4 triangular sweeps, r128,nt1,u1)
 	int nb1 = 1;  // one block slot per row (bs=4: 8 lanes per row, 8 rows per wave; bs=8: 32 lanes, 2 rows); 0 = two slots, 3 = triangular sweeps only
 };
 
@@ -348,13 +371,14 @@ static Variant parse_variant(const char *e)
 		v.enabled = 0;
 		return v;
 	}
-	int r = 128, nt = 1, unr = 1, nb1 = 1;
-	const int got = std::sscanf(e, "r%d,nt%d,u%d,s%d", &r, &nt, &unr, &nb1);
+	int r = 128, nt = 1, unr = 1, nb1 = 1, sc = 0;
+	const int got = std::sscanf(e, "r%d,nt%d,u%d,s%d,c%d", &r, &nt, &unr, &nb1, &sc);
 	if (got >= 3) {
 		v.rchunk = r;
 		v.nt = nt;
 		v.unr = unr;
-		if (got == 4)
+		v.sc = (got == 5 && sc == 1) ? 1 : 0;
+		if (got >= 4)
 			v.nb1 = nb1 == 1 ? 1 : (nb1 == 3 ? 3 : 0);  // ",s1" (default): one block slot per row; ",s2": two; ",s3": one for the triangular sweeps only
 	}
 	return v;
@@ -391,7 +415,12 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		   9.8e-4, i.e. the contraction per sweep from 0.444 to 0.471 = 8 % more sweeps for the same       \
 		   accuracy.  The default is therefore u1. */                                                      \
 		constexpr int UN1 = (BS == 4 && (PART == PART_LOWER || PART == PART_UPPER)) ? UV : 1;            \
-		if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                         \
+		constexpr bool SCOK = BS == 4 && RV == 128 && NTV == 1 && UV == 1 &&                            \
+		                      (PART == PART_LOWER || PART == PART_UPPER);                               \
+		if (v.sc && SCOK)                                                                              \
+			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, true, 1, 1, SCOK>), dim3(grid),  \
+			                   dim3(256), 0, s, a);                                                    \
+		else if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                    \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \
 			                   dim3(256), 0, s, a);                                                    \
 		else                                                                                           \

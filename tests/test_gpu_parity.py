@@ -375,6 +375,43 @@ def test_sgs_async_converges_to_exact(golden, case):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "poisson16_bs4", "poisson12_bs5",
+                                  "poisson9_bs8", "random_bs4", "random_bs5", "random_csr"])
+def test_sgs_apply_forward_half_is_exact_at_low_sweep_counts(golden, case):
+    """Q3 (src/solverops_sgs.cpp:62-66, kernels_sgs.hpp:127): the reference's forward loop is outside the
+    parallel region, so ytemp = (D+L)^-1 r is the exact serial solve at every sweep and thread count; only
+    the backward sweeps are asynchronous.  The product (ASYNC) mode must give that ytemp at the reference's
+    own low sweep counts, and a z no farther from the exact backward solve than synchronous Jacobi backward
+    sweeps from the same y (the serial Gauss-Seidel sweep is the exact solve, distance 0)."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    ze, ye = O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO, return_y=True)
+    for nsw in (1, 3):
+        for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+            z = p.sgs_apply(r, nsw, init=init, mode=capi.ASYNC)
+            assert rel(p.get_ytemp(), ye) < 1e-12
+            # the oracle's threaded mode keeps the forward half serial as well
+            zo, yo = O.sgs_apply(m, gd, r, nsw, mode=O.ASYNC_OMP, init=init, return_y=True)
+            assert rel(yo, ye) < 1e-13
+            # exact forward half + nsw synchronous Jacobi backward sweeps (ye is a fixed point of the forward sweep)
+            z0 = np.zeros(n) if init == capi.INIT_A_ZERO else ye
+            zj = O.sgs_apply(m, gd, r, nsw, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=z0)
+            dj, dg = np.linalg.norm(zj - ze), np.linalg.norm(z - ze)
+            assert dg <= 1.05 * dj + 1e-12 * np.linalg.norm(ze)
+    # the all-asynchronous form of round 1 stays reachable as a tuning variant and differs at one sweep
+    capi.set_tuning("sgsfwd=async")
+    try:
+        p.sgs_apply(r, 1, init=capi.INIT_A_ZERO, mode=capi.ASYNC)
+        assert rel(p.get_ytemp(), ye) > 1e-6
+    finally:
+        capi.set_tuning("sgsfwd=exact")
+    p.close()
+
+
 def test_sgs_relax_async_reduces_residual(golden):
     """config 3: async block-SGS relaxation, 5 sweeps; asynchronous result lies between the
     synchronous-Jacobi and the serial Gauss-Seidel iterates in residual."""
