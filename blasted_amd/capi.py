@@ -29,6 +29,7 @@ SYMBOLS = [
     "blasted_hip_set_tuning",
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
     "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
+    "blasted_hip_device_synchronize", "blasted_hip_memory_stats",
 ]
 
 _lib = None
@@ -76,6 +77,7 @@ def lib():
         _lib.blasted_hip_level_count.argtypes = [vp, C.POINTER(ci)]
         _lib.blasted_hip_get_levels.argtypes = [vp, vp, vp, vp]
         _lib.blasted_hip_level_stats.argtypes = [vp, vp]
+        _lib.blasted_hip_memory_stats.argtypes = [vp, vp]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
         for nm in ("iluvals", "dblocks", "scale", "ytemp"):
@@ -83,6 +85,10 @@ def lib():
         _lib.blasted_hip_iluvals_device.argtypes = [vp, C.POINTER(vp)]
         _lib.blasted_hip_set_timing.argtypes = [vp, ci]
         _lib.blasted_hip_get_timing.argtypes = [vp, vp, ci]
+        # measurements: BLASTED_HIP_TUNING="spec;spec;..." applies blasted_hip_set_tuning strings at load time
+        for spec in filter(None, os.environ.get("BLASTED_HIP_TUNING", "").split(";")):
+            if _lib.blasted_hip_set_tuning(spec.encode()) != OK:
+                raise ValueError("BLASTED_HIP_TUNING: bad tuning string %r" % spec)
     return _lib
 
 
@@ -270,6 +276,11 @@ class Prec:
         out = (C.c_long * 4)()
         _check(lib().blasted_hip_level_stats(self._h, C.cast(out, C.c_void_p)))
         return dict(zip(("levels", "build_passes", "syncfree_passes", "syncfree_aborts"), [int(v) for v in out]))
+
+    def memory_stats(self):
+        out = (C.c_long * 4)()
+        _check(lib().blasted_hip_memory_stats(self._h, out))
+        return {"bytes": out[0], "peak_bytes": out[1], "derived_copies": out[2], "pinned_host_bytes": out[3]}
 
     def get_levels(self):
         """-> (level_of_row[nbrows], rows_by_level[nbrows], level_ptr[nlevels+1]) int32 numpy arrays."""

@@ -5,7 +5,9 @@
 #include "ctx.hpp"
 
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <vector>
 
 namespace bhip {
 
@@ -24,24 +26,87 @@ void trace_alloc(const void *p, size_t bytes)
 		std::fprintf(stderr, "[blasted_hip] alloc %12zu B at %p\n", bytes, p);
 }
 
+// ---- device memory accounting ------------------------------------------------------------------
+static thread_local blasted_hip_prec tl_owner = nullptr;  // the operator whose entry point runs on this thread
+
+namespace {
+struct AllocRegistry {
+	struct Rec {
+		size_t bytes;
+		blasted_hip_prec owner;
+	};
+	std::mutex mu;
+	std::map<void *, Rec> recs;
+};
+AllocRegistry &alloc_registry()
+{
+	static AllocRegistry *r = new AllocRegistry;  // never destroyed: operators may be freed at process exit
+	return *r;
+}
+}  // namespace
+
+hipError_t tracked_malloc(void **p, size_t bytes)
+{
+	const hipError_t e = hipMalloc(p, bytes);
+	if (e != hipSuccess)
+		return e;
+	trace_alloc(*p, bytes);
+	AllocRegistry &r = alloc_registry();
+	std::lock_guard<std::mutex> lk(r.mu);
+	r.recs[*p] = {bytes, tl_owner};
+	if (tl_owner) {
+		tl_owner->bytes_owned += (long)bytes;
+		if (tl_owner->bytes_owned > tl_owner->bytes_peak)
+			tl_owner->bytes_peak = tl_owner->bytes_owned;
+	}
+	return e;
+}
+
+hipError_t tracked_free(void *p)
+{
+	if (p) {
+		AllocRegistry &r = alloc_registry();
+		std::lock_guard<std::mutex> lk(r.mu);
+		auto it = r.recs.find(p);
+		if (it != r.recs.end()) {
+			if (it->second.owner)
+				it->second.owner->bytes_owned -= (long)it->second.bytes;
+			r.recs.erase(it);
+		}
+	}
+	return hipFree(p);
+}
+
+// an operator that goes away must not be booked on any more
+static void forget_owner(blasted_hip_prec p)
+{
+	AllocRegistry &r = alloc_registry();
+	std::lock_guard<std::mutex> lk(r.mu);
+	for (auto &kv : r.recs)
+		if (kv.second.owner == p)
+			kv.second.owner = nullptr;
+}
+
 template <typename T>
 static T *dev_alloc(size_t count)
 {
 	T *p = nullptr;
-	BHIP_CHECK(hipMalloc(&p, sizeof(T) * (count ? count : 1)));
-	trace_alloc(p, sizeof(T) * count);
+	BHIP_CHECK(tracked_malloc(&p, sizeof(T) * (count ? count : 1)));
 	return p;
 }
 
 static void dev_free(void *p)
 {
 	if (p)
-		(void)hipFree(p);
+		(void)tracked_free(p);
 }
 
 template <typename F>
 static int guarded(F &&f)
 {
+	struct OwnerReset {
+		~OwnerReset() { tl_owner = nullptr; }
+	} reset;
 	try {
 		f();
 		return BLASTED_HIP_OK;
@@ -58,6 +123,7 @@ static void use_device(blasted_hip_prec p)
 	if (!p)
 		BHIP_FAIL(BLASTED_HIP_EINVAL, "null blasted_hip_prec");
 	BHIP_CHECK(hipSetDevice(p->device));
+	tl_owner = p;
 }
 
 static void need_pattern(blasted_hip_prec p)
@@ -135,6 +201,91 @@ struct Phase {
 	}
 };
 
+// ---- pinned staging of caller-owned host arrays ----------------------------------------------
+// PETSc hands the PCSHELL callbacks plain pageable arrays (VecGetArray, the Mat's value array), and a Krylov
+// solver hands over the SAME few work vectors again and again.  A host range that is seen a second time is
+// page-locked in place (hipHostRegister), so that every later copy is a direct DMA instead of a staged
+// pageable copy; ranges seen once never pay for a registration.  A small process-wide LRU table; entries are
+// unregistered when they fall out or at process exit.  BLASTED_HIP_PIN=0 switches it off.  (A range the
+// caller frees while registered is harmless: ROCm tracks registered ranges through MMU notifiers, and the
+// stale entry is evicted like any other.)
+namespace {
+
+struct PinTable {
+	struct Ent {
+		uintptr_t lo, hi;
+		unsigned long stamp;
+		bool registered;
+	};
+	std::mutex mu;
+	std::vector<Ent> ents;
+	unsigned long clock = 0;
+	long registered_bytes = 0, registrations = 0;
+	bool enabled = [] {
+		const char *e = std::getenv("BLASTED_HIP_PIN");
+		return !(e && e[0] == '0');
+	}();
+
+	~PinTable()
+	{
+		for (auto &e : ents)
+			if (e.registered)
+				(void)hipHostUnregister(reinterpret_cast<void *>(e.lo));
+	}
+
+	void touch(const void *p, size_t nbytes)
+	{
+		constexpr size_t MIN_BYTES = 1u << 20;
+		constexpr size_t MAX_ENTS = 16;
+		if (!enabled || !p || nbytes < MIN_BYTES)
+			return;
+		const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + nbytes;
+		std::lock_guard<std::mutex> lk(mu);
+		clock++;
+		for (size_t i = 0; i < ents.size(); i++) {
+			Ent &e = ents[i];
+			if (lo >= e.lo && hi <= e.hi) {  // seen before
+				e.stamp = clock;
+				if (!e.registered) {
+					if (hipHostRegister(reinterpret_cast<void *>(e.lo), e.hi - e.lo, hipHostRegisterDefault) == hipSuccess) {
+						e.registered = true;
+						registered_bytes += (long)(e.hi - e.lo);
+						registrations++;
+					} else {
+						(void)hipGetLastError();  // not pinnable: stays pageable, never retried
+						e.lo = e.hi = 0;
+					}
+				}
+				return;
+			}
+			if (lo < e.hi && hi > e.lo) {  // overlaps an old entry without lying inside it: that entry is stale
+				if (e.registered) {
+					(void)hipHostUnregister(reinterpret_cast<void *>(e.lo));
+					registered_bytes -= (long)(e.hi - e.lo);
+				}
+				ents.erase(ents.begin() + (long)i);
+				i--;
+			}
+		}
+		if (ents.size() >= MAX_ENTS) {
+			size_t victim = 0;
+			for (size_t i = 1; i < ents.size(); i++)
+				if (ents[i].stamp < ents[victim].stamp)
+					victim = i;
+			if (ents[victim].registered) {
+				(void)hipHostUnregister(reinterpret_cast<void *>(ents[victim].lo));
+				registered_bytes -= (long)(ents[victim].hi - ents[victim].lo);
+			}
+			ents.erase(ents.begin() + (long)victim);
+		}
+		ents.push_back({lo, hi, clock, false});  // first sighting: remember, do not register yet
+	}
+};
+
+PinTable g_pins;
+
+}  // namespace
+
 // ---- host <-> device vector staging --------------------------------------------------------
 
 // Returns a device pointer holding the caller's input vector.
@@ -143,6 +294,7 @@ static const double *in_vec(blasted_hip_prec p, const double *v, int loc, int sl
 	if (loc == BLASTED_HIP_DEVICE)
 		return v;
 	double *d = ensure(p->stage[slot], p->n());
+	g_pins.touch(v, sizeof(double) * (size_t)p->n());
 	BHIP_CHECK(hipMemcpyAsync(d, v, sizeof(double) * p->n(), hipMemcpyHostToDevice, p->stream));
 	return d;
 }
@@ -158,6 +310,7 @@ static void finish_out(blasted_hip_prec p, double *host, const double *dev, int 
 {
 	if (loc == BLASTED_HIP_DEVICE)
 		return;
+	g_pins.touch(host, sizeof(double) * (size_t)p->n());
 	BHIP_CHECK(hipMemcpyAsync(host, dev, sizeof(double) * p->n(), hipMemcpyDeviceToHost, p->stream));
 	BHIP_CHECK(hipStreamSynchronize(p->stream));
 }
@@ -204,19 +357,40 @@ static int g_compact = [] {
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 }();
 
-// Brings the two-triangle copy `c` of the block array `src` up to date in the storage `st`.
+// tuning ("copies=one" default / "copies=both"): the natural-order copy (asynchronous sweeps) and the
+// level-ordered copy (exact solves) of the same array are alternatives -- an operator type uses one of them
+// -- so by default only the one last asked for stays resident: block array + one derived copy = two copies
+// (256^3 bs=4: 30 GB instead of 45 GB for an operator that has been applied both ways).  The rule is applied
+// per TRIANGLE: the product-mode SGS application, whose forward half is an exact solve and whose backward half
+// are asynchronous sweeps, holds the level-ordered lower and the natural-order upper triangle -- one copy's
+// worth.  A program that alternates the two kinds of application on ONE operator pays a copy pass per
+// switch (6 ms for both triangles at 256^3); "copies=both" keeps both orderings.
+static int g_keep_both_copies = [] {
+	const char *e = std::getenv("BLASTED_HIP_COPIES");
+	return (e && std::strcmp(e, "both") == 0) ? 1 : 0;
+}();
+
+// Brings one triangle of the two-triangle copy `c` of the block array `src` up to date in the storage `st`;
+// `other` is the copy of the same array in the other ordering, whose same triangle is given up (see above).
 static void refresh_copy(blasted_hip_prec p, const LevelSchedule &st, const double *src,
-                         blasted_hip_prec_s::TriCopy &c)
+                         blasted_hip_prec_s::TriCopy &c, blasted_hip_prec_s::TriCopy &other, const bool upper)
 {
 	const long bs2 = (long)p->pat.bs * p->pat.bs;
-	if (!c.l) {
-		c.l = dev_alloc<double>((size_t)(st.nnz_lower * bs2));
-		c.u = dev_alloc<double>((size_t)(st.nnz_dupper * bs2));
-		c.valid = false;
+	double *&mine = upper ? c.u : c.l;
+	bool &valid = upper ? c.valid_u : c.valid_l;
+	if (!mine) {
+		if (!g_keep_both_copies) {
+			double *&theirs = upper ? other.u : other.l;
+			dev_free(theirs);
+			theirs = nullptr;
+			(upper ? other.valid_u : other.valid_l) = false;
+		}
+		mine = dev_alloc<double>((size_t)((upper ? st.nnz_dupper : st.nnz_lower) * bs2));
+		valid = false;
 	}
-	if (!c.valid) {
-		launch_level_permute_values(p->pat, st, src, c.l, c.u, p->stream);
-		c.valid = true;
+	if (!valid) {
+		launch_level_permute_values(p->pat, st, src, upper ? nullptr : c.l, upper ? c.u : nullptr, p->stream);
+		valid = true;
 	}
 }
 
@@ -228,7 +402,7 @@ static void compact_args(blasted_hip_prec p, bool upper, SweepArgs &a, const dou
 {
 	LevelSchedule &ns = p->natstore;
 	build_natural_storage(p->pat, ns, p->stream);
-	refresh_copy(p, ns, src, c);
+	refresh_copy(p, ns, src, c, &c == &p->fac_nat ? p->fac_lvl : p->mat_lvl, upper);
 	if (upper) {
 		a.pat.browptr = ns.uptr;
 		a.pat.diagind = ns.uptr;  // the diagonal block is the first of a row of this copy
@@ -253,7 +427,7 @@ static bool level_view(blasted_hip_prec p, bool upper, LevelView &v, const doubl
 		return false;
 	LevelSchedule &ls = need_levels(p);
 	build_level_storage(p->pat, ls, p->stream);
-	refresh_copy(p, ls, src, c);
+	refresh_copy(p, ls, src, c, &c == &p->fac_lvl ? p->fac_nat : p->mat_nat, upper);
 	v.meta = upper ? ls.umeta : ls.lmeta;
 	v.ptr = upper ? ls.uptr : ls.lptr;
 	v.head = upper ? ls.uhead : ls.lhead;
@@ -490,6 +664,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 			return;
 		(void)hipSetDevice(p->device);
 		(void)hipStreamSynchronize(p->stream);
+		tl_owner = p;
 		for (auto &r : p->timing.recs) {
 			(void)hipEventDestroy(r.e0);
 			(void)hipEventDestroy(r.e1);
@@ -525,6 +700,8 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		}
 		if (p->own_stream)
 			(void)hipStreamDestroy(p->stream);
+		forget_owner(p);
+		tl_owner = nullptr;
 		delete p;
 	});
 }
@@ -534,6 +711,19 @@ int blasted_hip_synchronize(blasted_hip_prec p)
 	return guarded([&] {
 		use_device(p);
 		BHIP_CHECK(hipStreamSynchronize(p->stream));
+	});
+}
+
+int blasted_hip_device_synchronize(int device)
+{
+	return guarded([&] {
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+			BHIP_FAIL(BLASTED_HIP_ENODEV, "no HIP device available: the MI355X backend has no CPU fallback");
+		if (device < 0 || device >= n)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "device index out of range");
+		BHIP_CHECK(hipSetDevice(device));
+		BHIP_CHECK(hipDeviceSynchronize());
 	});
 }
 
@@ -616,13 +806,14 @@ int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
 		} else {
 			if (!p->vals_own)
 				p->vals_own = dev_alloc<double>((size_t)p->nvals());
+			g_pins.touch(vals, sizeof(double) * (size_t)p->nvals());
 			BHIP_CHECK(hipMemcpyAsync(p->vals_own, vals, sizeof(double) * (size_t)p->nvals(),
 			                          hipMemcpyHostToDevice, p->stream));
 			BHIP_CHECK(hipStreamSynchronize(p->stream));
 			p->vals = p->vals_own;
 		}
-		p->mat_nat.valid = false;
-		p->mat_lvl.valid = false;
+		p->mat_nat.invalidate();
+		p->mat_lvl.invalidate();
 	});
 }
 
@@ -677,8 +868,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
-		p->fac_lvl.valid = false;
-		p->fac_nat.valid = false;
+		p->fac_lvl.invalidate();
+		p->fac_nat.invalidate();
 		p->fdiag_valid = false;
 		if (mode == BLASTED_HIP_LEVEL)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
@@ -958,8 +1149,8 @@ int blasted_hip_jacobi_compute(blasted_hip_prec p)
 		ph.launches = 1;
 		ph.done();
 		p->jacobi_done = true;
-		p->mat_nat.valid = false;  // compute(): the borrowed values may have changed in place
-		p->mat_lvl.valid = false;
+		p->mat_nat.invalidate();  // compute(): the borrowed values may have changed in place
+		p->mat_lvl.invalidate();
 		if (!p->ytemp) {  // AsyncBlockSGS::compute, src/solverops_sgs.cpp:33-45
 			p->ytemp = dev_alloc<double>((size_t)p->n());
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, sizeof(double) * (size_t)p->n(), p->stream));
@@ -1328,6 +1519,23 @@ int blasted_hip_level_stats(blasted_hip_prec p, long *out4)
 	});
 }
 
+int blasted_hip_memory_stats(blasted_hip_prec p, long *out4)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!out4)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "memory_stats: null output");
+		out4[0] = p->bytes_owned;
+		out4[1] = p->bytes_peak;
+		int copies = 0;
+		for (const auto *c : {&p->fac_nat, &p->fac_lvl, &p->mat_nat, &p->mat_lvl})
+			copies += (c->l ? 1 : 0) + (c->u ? 1 : 0);
+		out4[2] = copies;  // in triangles: two = one copy's worth
+		std::lock_guard<std::mutex> lk(g_pins.mu);
+		out4[3] = g_pins.registered_bytes;
+	});
+}
+
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr)
 {
 	return guarded([&] {
@@ -1439,7 +1647,7 @@ int blasted_hip_buffer_alloc(void **dev_ptr, unsigned long nbytes, int device)
 		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
 			BHIP_FAIL(BLASTED_HIP_ENODEV, "no HIP device available: the MI355X backend has no CPU fallback");
 		BHIP_CHECK(hipSetDevice(device));
-		BHIP_CHECK(hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+		BHIP_CHECK(tracked_malloc(dev_ptr, nbytes ? nbytes : 1));  // no operator is running: booked on nobody
 	});
 }
 
@@ -1447,7 +1655,7 @@ int blasted_hip_buffer_free(void *dev_ptr)
 {
 	return guarded([&] {
 		if (dev_ptr)
-			BHIP_CHECK(hipFree(dev_ptr));
+			BHIP_CHECK(tracked_free(dev_ptr));
 	});
 }
 
@@ -1517,13 +1725,15 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "sweepwr=", 8) == 0)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
-			set_sweepodd_enabled(spec[9] != '0');
+			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : spec[9] != '0'));
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
 		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)
 			set_factorodd_enabled(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "relaxsplit=", 11) == 0)
 			g_relax_split = spec[11] != '0';
+		else if (spec && std::strncmp(spec, "copies=", 7) == 0)
+			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
 			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)

@@ -202,6 +202,17 @@ struct Timing {
 
 void trace_alloc(const void *p, size_t bytes);  // capi.hip
 
+// Device allocations of the library go through these two (capi.hip): same contract as hipMalloc / hipFree,
+// plus per-operator accounting -- the bytes are booked on the operator whose entry point is running on this
+// thread (blasted_hip_memory_stats), or on nobody (raw buffers handed to the caller).
+hipError_t tracked_malloc(void **p, size_t bytes);
+hipError_t tracked_free(void *p);
+template <typename T>
+inline hipError_t tracked_malloc(T **p, size_t bytes)
+{
+	return tracked_malloc(reinterpret_cast<void **>(p), bytes);
+}
+
 }  // namespace bhip
 
 struct blasted_hip_prec_s {
@@ -237,8 +248,9 @@ struct blasted_hip_prec_s {
 	// second copies of the factor and of the matrix, split into the strictly-lower and the diagonal+upper
 	// triangle: natural row order (asynchronous sweeps) and level order (exact passes)
 	struct TriCopy {
-		double *l = nullptr, *u = nullptr;
-		bool valid = false;
+		double *l = nullptr, *u = nullptr;  // each triangle is allocated and refreshed on its own
+		bool valid_l = false, valid_u = false;
+		void invalidate() { valid_l = valid_u = false; }
 	};
 	double *yperm = nullptr, *zperm = nullptr;  // level-ordered iterates of the exact ILU solves
 	bool y_in_level_order = false;              // yperm holds L^-1 r of the last exact apply, ytemp is stale
@@ -247,6 +259,8 @@ struct blasted_hip_prec_s {
 	TriCopy fac_nat, fac_lvl, mat_nat, mat_lvl;
 
 	bhip::Timing timing;
+
+	long bytes_owned = 0, bytes_peak = 0;  // device memory this operator holds (tracked_malloc)
 
 	long n() const { return (long)pat.nbrows * pat.bs; }
 	long nvals() const { return (long)pat.nnzb * pat.bs * pat.bs; }

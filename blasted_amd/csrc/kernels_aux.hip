@@ -108,7 +108,7 @@ static void inclusive_scan_device(int *data, long n, hipStream_t s)
 		return;
 	}
 	int *sums = nullptr;
-	BHIP_CHECK(hipMalloc(&sums, sizeof(int) * ntiles));
+	BHIP_CHECK(tracked_malloc(&sums, sizeof(int) * ntiles));
 	try {
 		hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, data, n, sums);
 		BHIP_CHECK(hipGetLastError());
@@ -119,10 +119,10 @@ static void inclusive_scan_device(int *data, long n, hipStream_t s)
 		BHIP_CHECK(hipGetLastError());
 		BHIP_CHECK(hipStreamSynchronize(s));
 	} catch (...) {
-		(void)hipFree(sums);
+		(void)tracked_free(sums);
 		throw;
 	}
-	BHIP_CHECK(hipFree(sums));
+	BHIP_CHECK(tracked_free(sums));
 }
 
 long run_ilu_positions(const Pattern &pat, int **posptr_out, int **lowerp_out, int **upperp_out,
@@ -130,7 +130,7 @@ long run_ilu_positions(const Pattern &pat, int **posptr_out, int **lowerp_out, i
 {
 	int *posptr = nullptr, *lowerp = nullptr, *upperp = nullptr;
 	const long nent = pat.nnzb;
-	BHIP_CHECK(hipMalloc(&posptr, sizeof(int) * (nent + 1)));
+	BHIP_CHECK(tracked_malloc(&posptr, sizeof(int) * (nent + 1)));
 	try {
 		BHIP_CHECK(hipMemsetAsync(posptr, 0, sizeof(int) * (nent + 1), s));
 		const unsigned grid = (unsigned)((pat.nbrows + 255) / 256);
@@ -145,8 +145,8 @@ long run_ilu_positions(const Pattern &pat, int **posptr_out, int **lowerp_out, i
 		BHIP_CHECK(hipStreamSynchronize(s));
 		if (total < 0)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ILU position list overflows the int32 index type");
-		BHIP_CHECK(hipMalloc(&lowerp, sizeof(int) * (total > 0 ? total : 1)));
-		BHIP_CHECK(hipMalloc(&upperp, sizeof(int) * (total > 0 ? total : 1)));
+		BHIP_CHECK(tracked_malloc(&lowerp, sizeof(int) * (total > 0 ? total : 1)));
+		BHIP_CHECK(tracked_malloc(&upperp, sizeof(int) * (total > 0 ? total : 1)));
 		if (grid && total > 0) {
 			hipLaunchKernelGGL(ilu_positions_kernel<true>, dim3(grid), dim3(256), 0, s, pat, posptr,
 			                   lowerp, upperp);
@@ -157,9 +157,9 @@ long run_ilu_positions(const Pattern &pat, int **posptr_out, int **lowerp_out, i
 		*upperp_out = upperp;
 		return total;
 	} catch (...) {
-		(void)hipFree(posptr);
-		(void)hipFree(lowerp);
-		(void)hipFree(upperp);
+		(void)tracked_free(posptr);
+		(void)tracked_free(lowerp);
+		(void)tracked_free(upperp);
 		throw;
 	}
 }
@@ -200,7 +200,7 @@ __global__ void validate_kernel(const Pattern pat, int *flags)
 int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len)
 {
 	int *flags = nullptr;
-	BHIP_CHECK(hipMalloc(&flags, 2 * sizeof(int)));
+	BHIP_CHECK(tracked_malloc(&flags, 2 * sizeof(int)));
 	int h[2] = {0, 0};
 	try {
 		BHIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), s));
@@ -212,10 +212,10 @@ int validate_pattern_device(const Pattern &pat, hipStream_t s, int *max_row_len)
 		BHIP_CHECK(hipMemcpyAsync(h, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
 		BHIP_CHECK(hipStreamSynchronize(s));
 	} catch (...) {
-		(void)hipFree(flags);
+		(void)tracked_free(flags);
 		throw;
 	}
-	BHIP_CHECK(hipFree(flags));
+	BHIP_CHECK(tracked_free(flags));
 	if (max_row_len)
 		*max_row_len = h[1];
 	return h[0];

@@ -583,12 +583,16 @@ __global__ __launch_bounds__(256) void level_permute_kernel(const Pattern pat, c
 	const long nl = (dg - rp0) * BS2, nu = (rp1 - dg) * BS2;
 	const double *const srcl = vals + rp0 * BS2;
 	const double *const srcu = vals + dg * BS2;
-	double *const dstl = lvals + (long)lptr[k] * BS2;
-	double *const dstu = uvals + (long)uptr[k] * BS2;
-	for (long q = t; q < nl; q += 16)
-		dstl[q] = srcl[q];
-	for (long q = t; q < nu; q += 16)
-		dstu[q] = srcu[q];
+	if (lvals) {  // (either triangle may be left out)
+		double *const dstl = lvals + (long)lptr[k] * BS2;
+		for (long q = t; q < nl; q += 16)
+			dstl[q] = srcl[q];
+	}
+	if (uvals) {
+		double *const dstu = uvals + (long)uptr[k] * BS2;
+		for (long q = t; q < nu; q += 16)
+			dstu[q] = srcu[q];
+	}
 }
 
 
@@ -596,8 +600,7 @@ template <typename T>
 T *lvl_alloc(size_t count)
 {
 	void *q = nullptr;
-	BHIP_CHECK(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
-	trace_alloc(q, sizeof(T) * count);
+	BHIP_CHECK(tracked_malloc(&q, sizeof(T) * (count ? count : 1)));
 	return static_cast<T *>(q);
 }
 
@@ -611,18 +614,18 @@ void set_syncfree_one_step(int on)
 void free_level_schedule(LevelSchedule &ls)
 {
 	if (ls.rows)
-		(void)hipFree(ls.rows);
+		(void)tracked_free(ls.rows);
 	if (ls.level)
-		(void)hipFree(ls.level);
+		(void)tracked_free(ls.level);
 	if (ls.meta)
-		(void)hipFree(ls.meta);
+		(void)tracked_free(ls.meta);
 	if (ls.ctl)
-		(void)hipFree(ls.ctl);
+		(void)tracked_free(ls.ctl);
 	for (void *q : {(void *)ls.lptr, (void *)ls.uptr, (void *)ls.lcol, (void *)ls.ucol, (void *)ls.lmeta,
 	                (void *)ls.umeta, (void *)ls.lhead, (void *)ls.uhead, (void *)ls.posof, (void *)ls.lcolp,
 	                (void *)ls.ucolp, (void *)ls.lheadp, (void *)ls.uheadp})
 		if (q)
-			(void)hipFree(q);
+			(void)tracked_free(q);
 	ls = LevelSchedule();
 }
 
@@ -667,7 +670,7 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(256), 0, s, iota, n);
 		size_t bytes = 0;
 		BHIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, level, keys, iota, rows, n, 0, 31, s));
-		BHIP_CHECK(hipMalloc(&tmp, bytes ? bytes : 1));
+		BHIP_CHECK(tracked_malloc(&tmp, bytes ? bytes : 1));
 		BHIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, level, keys, iota, rows, n, 0, 31, s));
 		int maxlevel = 0;
 		BHIP_CHECK(hipMemcpyAsync(&maxlevel, keys + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
@@ -707,19 +710,19 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		ls.built = true;
 	} catch (...) {
 		if (ls.meta)
-			(void)hipFree(ls.meta);
+			(void)tracked_free(ls.meta);
 		if (ls.ctl)
-			(void)hipFree(ls.ctl);
+			(void)tracked_free(ls.ctl);
 		ls.meta = nullptr;
 		ls.ctl = nullptr;
 		for (void *q : {(void *)level, (void *)keys, (void *)iota, (void *)rows, (void *)flags, (void *)dptr, tmp})
 			if (q)
-				(void)hipFree(q);
+				(void)tracked_free(q);
 		throw;
 	}
 	for (void *q : {(void *)keys, (void *)iota, (void *)flags, (void *)dptr, tmp})
 		if (q)
-			(void)hipFree(q);
+			(void)tracked_free(q);
 }
 
 // One exact in-order pass of the operator, in place on a.xout (a.xin must equal a.xout), as
@@ -820,7 +823,7 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		ls.uptr = lvl_alloc<int>((size_t)n + 1);
 		size_t bytes = 0;
 		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cl, ls.lptr, n + 1, s));
-		BHIP_CHECK(hipMalloc(&tmp, bytes ? bytes : 1));
+		BHIP_CHECK(tracked_malloc(&tmp, bytes ? bytes : 1));
 		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cl, ls.lptr, n + 1, s));
 		BHIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cu, ls.uptr, n + 1, s));
 		int tot[2] = {0, 0};
@@ -852,12 +855,12 @@ void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 	} catch (...) {
 		for (void *q : {(void *)cl, (void *)cu, tmp})
 			if (q)
-				(void)hipFree(q);
+				(void)tracked_free(q);
 		throw;
 	}
 	for (void *q : {(void *)cl, (void *)cu, tmp})
 		if (q)
-			(void)hipFree(q);
+			(void)tracked_free(q);
 }
 
 void launch_level_unpermute(const LevelSchedule &ls, int bs, const double *xperm, double *xnat, hipStream_t s)

@@ -155,17 +155,28 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 					} else
 						acc += bv[q][k] * xv[q][k];  // xv is zero for skipped / absent items
 				}
-				for (int jj = jbeg[q] + slot + KFIX * NB; jj < jend[q]; jj += NB) {
-					if (PART == PART_OFFDIAG && jj == dg[q])
-						continue;
-					if (active) {
-						const int cidx = jj - jlo;
-						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-						acc += *reinterpret_cast<const double *>(
-						           vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e)) *
-						       *reinterpret_cast<const double *>(
-						           xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+				// longer rows: the rest in groups of KGRP predicated straight-line passes -- one memory round
+				// trip per group instead of one per pass
+				constexpr int KGRP = 4;
+				for (int jb = jbeg[q] + slot + KFIX * NB; jb < jend[q]; jb += KGRP * NB) {
+					double v4[KGRP], x4[KGRP];
+#pragma unroll
+					for (int k = 0; k < KGRP; k++) {
+						const int jj = jb + k * NB;
+						v4[k] = 0.0;
+						x4[k] = 0.0;
+						if (jj < jend[q] && active && !(PART == PART_OFFDIAG && jj == dg[q])) {
+							const int cidx = jj - jlo;
+							const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+							v4[k] = *reinterpret_cast<const double *>(
+							    vbase + ((unsigned)(jj - jlo) * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+							x4[k] = *reinterpret_cast<const double *>(
+							    xbase + ((unsigned)col * (unsigned)(BS * 8) + 8u * (unsigned)c));
+						}
 					}
+#pragma unroll
+					for (int k = 0; k < KGRP; k++)
+						acc += v4[k] * x4[k];
 				}
 				acc = allreduce_bits<Ge::LOBIT, Ge::HIBIT>(acc);  // lanes (r,*,*) now hold row r of the sum
 			}

@@ -41,7 +41,8 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 	return __builtin_nontemporal_load(reinterpret_cast<const d2u_t *>(p));
 }
 
-template <int BS, int PART, int POST, int DSRC, int RCHUNK>
+// NT: the block stream is read with non-temporal loads (tuning "sweepodd=nt0" / "sweepodd=nt1").
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true>
 __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 {
 	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 			xv[k].x = xv[k].y = 0.0;
 			// (relaxation: the diagonal block of A is not part of the sum -- do not fetch it)
 			if (PART != PART_NONE && jj < jend && actB && !(PART == PART_OFFDIAG && jj == dg)) {
-				bv[k] = load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
+				bv[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
+				           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
 				const bool isdiag = (jj == dg);
 				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {
 					const int cidx = jj - jlo;
@@ -147,16 +149,29 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 					accB += bv[k].y * (hiB ? xv[k].y : xv[k].x);
 				}
 			}
-			for (int jj = jbeg + KFIX; jj < jend; jj++) {
-				if (PART == PART_OFFDIAG && jj == dg)
-					continue;
-				if (actB) {
-					const d2_t v2 = load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
-					const int cidx = jj - jlo;
-					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					const d2_t x2 = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
-					accA += v2.x * (hiA ? x2.y : x2.x);
-					accB += v2.y * (hiB ? x2.y : x2.x);
+			// rows longer than KFIX blocks (unstructured meshes: ~7 lower and ~8 diagonal+upper blocks at 14
+			// neighbours): the rest goes in groups of KGRP predicated straight-line passes, one memory round
+			// trip per group -- one block per iteration made every extra block a dependent round trip
+			constexpr int KGRP = 4;
+			for (int jb = jbeg + KFIX; jb < jend; jb += KGRP) {
+				d2_t v4[KGRP], x4[KGRP];
+#pragma unroll
+				for (int k = 0; k < KGRP; k++) {
+					const int jj = jb + k;
+					v4[k].x = v4[k].y = 0.0;
+					x4[k].x = x4[k].y = 0.0;
+					if (jj < jend && actB && !(PART == PART_OFFDIAG && jj == dg)) {
+						v4[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
+						           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						x4[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < KGRP; k++) {
+					accA += v4[k].x * (hiA ? x4[k].y : x4[k].x);
+					accB += v4[k].y * (hiB ? x4[k].y : x4[k].x);
 				}
 			}
 			// 25 partial products -> 5 components through the wave-private tile
@@ -211,6 +226,8 @@ int g_sweepodd_enabled = [] {
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 }();
 
+int g_sweepodd_nt = 1;  // tuning "sweepodd=nt0" / "sweepodd=nt1": bs=5 block stream with plain / non-temporal loads
+
 template <int PART, int POST, int DSRC>
 void launch5(const SweepArgs &a, hipStream_t s)
 {
@@ -218,7 +235,12 @@ void launch5(const SweepArgs &a, hipStream_t s)
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
 	switch (a.pat.bs) {
 	case 3: hipLaunchKernelGGL((sweepodd_kernel<3, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
-	case 5: hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
+	case 5:
+		if (g_sweepodd_nt)
+			hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK, true>), dim3(grid), dim3(256), 0, s, a);
+		else
+			hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK, false>), dim3(grid), dim3(256), 0, s, a);
+		break;
 	default: hipLaunchKernelGGL((sweepodd_kernel<7, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
 	}
 }
@@ -227,7 +249,10 @@ void launch5(const SweepArgs &a, hipStream_t s)
 
 void set_sweepodd_enabled(int on)
 {
-	g_sweepodd_enabled = on;
+	if (on == 2 || on == 3)  // "sweepodd=nt1" / "sweepodd=nt0"
+		g_sweepodd_nt = on == 2 ? 1 : 0;
+	else
+		g_sweepodd_enabled = on;
 }
 
 // returns false when the tuned kernel does not cover the request (caller uses the generic family)

@@ -282,17 +282,31 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 						acc1 += bv[u][k].y * xv[u][k];
 					}
 				}
-				for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
-					if (PART == PART_OFFDIAG && jj == dgp[u])
-						continue;
-					const double2_t v2 = load_block16<NT>(reinterpret_cast<const double *>(
-					    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
-					const int cidx = jj - jlo;
-					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
-					const double xc = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
-					acc0 += v2.x * xc;
-					acc1 += v2.y * xc;
+				// longer rows: the rest in groups of KGRP predicated straight-line passes -- one memory round
+				// trip per group instead of one per block
+				constexpr int KGRP = 4;
+				for (int jb = jbeg[u] + slot + KFIX * NB; jb < jend[u]; jb += KGRP * NB) {
+					double2_t v4[KGRP];
+					double x4[KGRP];
+#pragma unroll
+					for (int k = 0; k < KGRP; k++) {
+						const int jj = jb + k * NB;
+						v4[k].x = v4[k].y = 0.0;
+						x4[k] = 0.0;
+						if (jj < jend[u] && !(PART == PART_OFFDIAG && jj == dgp[u])) {
+							v4[k] = load_block16<NT>(reinterpret_cast<const double *>(
+							    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+							const int cidx = jj - jlo;
+							const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+							const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
+							x4[k] = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < KGRP; k++) {
+						acc0 += v4[k].x * x4[k];
+						acc1 += v4[k].y * x4[k];
+					}
 				}
 				// over the column bits and the block-slot bit; the row-pair bits h stay
 				acc0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(acc0);

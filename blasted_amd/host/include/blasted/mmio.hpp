@@ -1,4 +1,4 @@
-// mmio.hpp -- Matrix Market input for the native (non-PETSc) route.  It provides what a driver written against
+// mmio.hpp -- Matrix Market and PETSc-binary input for the native (non-PETSc) route.  It provides what a driver written against
 // the reference's include/coomatrix.hpp uses (tests/testsolve.cpp:60-107): COOMatrix, getSRMatrixFromCOO,
 // readDenseMatrixMarket, MatrixReadException and the MM* header enums; `coomatrix.hpp` forwards here.
 // Deliberate differences:
@@ -52,6 +52,11 @@ public:
 	/// getRowPtrs() delimits the rows
 	void readMatrixMarket(const std::string file);
 
+	/// Reads a PETSc binary AIJ matrix (what the reference's PETSc drivers load with MatLoad: the *.pmat
+	/// fixtures of tests/input): big-endian {int32 classid 1211216, rows, cols, nnz, int32 rowlengths[rows],
+	/// int32 colidx[nnz], float64 values[nnz]}.  Same post-conditions as readMatrixMarket.
+	void readPetscBinary(const std::string file);
+
 	index numrows() const;
 	index numcols() const;
 	index numnonzeros() const;
@@ -67,6 +72,8 @@ public:
 	SRMatrixStorage<scalar, index> convertToBSR() const;
 
 protected:
+	void sortEntries();  // by (row, column), stable; fills rowptr
+
 	index nrows = 0, ncols = 0, nnz = 0;
 	std::vector<Entry<scalar, index>> entries;  // sorted by (row, column)
 	std::vector<index> rowptr;                  // nrows + 1 offsets into entries
@@ -80,6 +87,13 @@ SRMatrixStorage<scalar, index> getSRMatrixFromCOO(const COOMatrix<scalar, index>
 /// The values of a dense "array ... general" file, in file order
 template <typename scalar>
 device_vector<scalar> readDenseMatrixMarket(const std::string file);
+
+/// The values of a PETSc binary vector (VecLoad's format: big-endian {int32 classid 1211214, n, float64 values[n]})
+template <typename scalar>
+device_vector<scalar> readPetscBinaryVector(const std::string file);
+
+/// The block size MatLoad would give the matrix in `file`: `-matload_block_size N` in `file`.info, 1 without it
+int petscBinaryBlockSize(const std::string file);
 
 /// What the banner line of a Matrix Market file says (names as in the reference, include/coomatrix.hpp:32-46)
 enum MMStorageType { COORDINATE, ARRAY };

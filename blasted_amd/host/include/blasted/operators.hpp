@@ -142,11 +142,19 @@ class SRPreconditioner : public Preconditioner<scalar, index> {
 public:
 	explicit SRPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix);
 	virtual ~SRPreconditioner();
-	/// apply / apply_relax on HBM-resident vectors (stream ordered; no host copy)
-	virtual void apply_device(const scalar *const dx, scalar *const dy) const;
-	virtual void apply_relax_device(const scalar *const db, scalar *const dx) const;
+	/// apply / apply_relax on HBM-resident vectors: the same operation as the host-vector member of the same
+	/// class, enqueued on the operator's stream (no host copy, no synchronisation).  Not in the reference.
+	void apply_device(const scalar *const dx, scalar *const dy) const { apply_at(dx, dy, 1); }
+	void apply_relax_device(const scalar *const db, scalar *const dx) const { relax_at(db, dx, 1); }
+	/// false for operators that have nothing to run on the device (NoPreconditioner)
+	virtual bool deviceVectorsAvailable() const { return true; }
 
 protected:
+	/// the one implementation behind apply / apply_device and apply_relax / apply_relax_device:
+	/// loc = 0 host vectors (BLASTED_HIP_HOST), 1 device vectors (BLASTED_HIP_DEVICE)
+	virtual void apply_at(const scalar *const x, scalar *const y, const int loc) const;
+	virtual void relax_at(const scalar *const b, scalar *const x, const int loc) const;
+
 	SRMatrixStorage<const scalar, const index> pmat;
 	CRawBSRMatrix<scalar, index> mat;
 	std::unique_ptr<detail::HipOperator> op;
@@ -158,6 +166,7 @@ public:
 	NoPreconditioner(SRMatrixStorage<const scalar, const index> &&matrix, const index bs);
 	index dim() const { return ndim; }
 	bool relaxationAvailable() const { return false; }
+	bool deviceVectorsAvailable() const { return false; }
 	PrecInfo compute() { return PrecInfo(); }
 	void apply(const scalar *const x, scalar *const __restrict y) const;
 	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
@@ -181,13 +190,14 @@ public:
 	/// synchronous Jacobi relaxation with the reference's optional convergence test on the step
 	/// difference (src/solverops_jacobi.cpp:66-119): solveparams.maxits, ctol, rtol, atol, dtol
 	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
-	void apply_device(const scalar *const dx, scalar *const dy) const;
 
 protected:
 	using SRPreconditioner<scalar, index>::mat;
 	using SRPreconditioner<scalar, index>::op;
 	using SRPreconditioner<scalar, index>::solveparams;
 	void bind_and_invert();
+	void apply_at(const scalar *const r, scalar *const z, const int loc) const;
+	void relax_at(const scalar *const b, scalar *const x, const int loc) const;
 };
 
 template <typename scalar, typename index>
@@ -211,13 +221,13 @@ public:
 	PrecInfo compute();
 	void apply(const scalar *const r, scalar *const __restrict z) const;
 	void apply_relax(const scalar *const b, scalar *const __restrict x) const;
-	void apply_device(const scalar *const dr, scalar *const dz) const;
-	void apply_relax_device(const scalar *const db, scalar *const dx) const;
 
 protected:
 	using SRPreconditioner<scalar, index>::mat;
 	using SRPreconditioner<scalar, index>::op;
 	using SRPreconditioner<scalar, index>::solveparams;
+	void apply_at(const scalar *const r, scalar *const z, const int loc) const;
+	void relax_at(const scalar *const b, scalar *const x, const int loc) const;
 	const int napplysweeps;
 	const ApplyInit ainit;
 	const int thread_chunk_size;
@@ -249,6 +259,8 @@ public:
 protected:
 	using SRPreconditioner<scalar, index>::op;
 	using SRPreconditioner<scalar, index>::solveparams;
+	void apply_at(const scalar *const b, scalar *const x, const int loc) const;
+	void relax_at(const scalar *const b, scalar *const x, const int loc) const;
 	const int napplysweeps;
 	const int thread_chunk_size;
 };
@@ -283,11 +295,12 @@ public:
 	void apply(const scalar *const x, scalar *const __restrict y) const;
 	/// throws std::runtime_error, as the reference does
 	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
-	void apply_device(const scalar *const dr, scalar *const dz) const;
 
 protected:
 	using SRPreconditioner<scalar, index>::mat;
 	using SRPreconditioner<scalar, index>::op;
+	void apply_at(const scalar *const r, scalar *const z, const int loc) const;
+	void relax_at(const scalar *const b, scalar *const x, const int loc) const;
 	const bool usescaling;
 	const bool threadedfactor;
 	const bool threadedapply;
@@ -334,6 +347,8 @@ public:
 protected:
 	using SRPreconditioner<scalar, index>::op;
 	using SRPreconditioner<scalar, index>::solveparams;
+	void apply_at(const scalar *const r, scalar *const z, const int loc) const;
+	void relax_at(const scalar *const b, scalar *const x, const int loc) const;
 };
 
 template <typename scalar, typename index>
@@ -357,11 +372,11 @@ public:
 	PrecInfo compute();
 	void apply(const scalar *const x, scalar *const __restrict y) const;
 	void apply_relax(const scalar *const x, scalar *const __restrict y) const;
-	void apply_device(const scalar *const dr, scalar *const dz) const;
 	int numLevels() const;
 
 protected:
 	using SRPreconditioner<scalar, index>::op;
+	void apply_at(const scalar *const r, scalar *const z, const int loc) const;
 };
 
 template <typename scalar, typename index>

@@ -62,6 +62,9 @@ void *device_buffer_alloc(std::size_t nbytes);
 void device_buffer_free(void *dev);
 void device_buffer_upload(void *dev, const void *host, std::size_t nbytes);
 void device_buffer_download(void *host, const void *dev, std::size_t nbytes);
+/// waits for everything enqueued on the operators' device, on any stream (callers that mix the operators'
+/// private streams with another library's, e.g. the PCSHELL glue on PETSc's HIP vectors)
+void device_synchronize();
 }  // namespace detail
 
 /// Aligned host array with an explicit mirror in HBM.  T must be plain old data.

@@ -5,10 +5,16 @@
 // differences:
 //  * the rank-local matrix is reached through PETSc's PUBLIC interface (MatGetRowIJ,
 //    MatSeqAIJGetArrayRead, MatSeqBAIJGetArray) instead of the private Mat_SeqAIJ / Mat_SeqBAIJ structs
-//    (src/blasted_petsc.cpp:14-15,285-297); the diagonal positions are found by one scan of the rows;
+//    (src/blasted_petsc.cpp:14-15,285-297).  The (block-)row structure is copied once per operator and
+//    handed back at once (MatRestoreRowIJ); the diagonal positions are found by one scan of the rows; the
+//    value array is taken out and handed back around every compute(), which is when the operator reads it
+//    (the values go to HBM there) -- a Mat whose value array moves gets a new operator;
 //  * bctx->prectype is set before it is consulted when the Richardson callback is installed (the
-//    reference reads it uninitialised).
-// Built only when PETSc is available (make petsc PETSC_DIR=... PETSC_ARCH=...).
+//    reference reads it uninitialised);
+//  * vectors that live in HBM (VECHIP / VECSEQHIP / VECMPIHIP, PETSc configured with HIP) are handed to the
+//    operator as device pointers (VecHIPGetArrayRead / VecHIPGetArrayWrite): r and z never cross PCIe.
+// Built where PETSc is available (make petsc PETSC_DIR=... PETSC_ARCH=...); in this repository it is also
+// built and executed against the test-only mini-PETSc of tests/petsc_stub (tests/test_gpu_petsc.py).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,9 +34,12 @@ typedef FactoryBase<PetscReal, PetscInt> BlastedFactory;
 
 namespace {
 
-/// borrowed PETSc arrays + the diagonal positions this glue owns, kept next to the operator
+/// what this glue owns next to an operator: its copy of the (block-)row structure, the diagonal positions,
+/// and the Mat / value array the operator was created on
 struct LocalMatrix {
-	std::vector<PetscInt> diag;
+	std::vector<PetscInt> ia, ja, diag;
+	Mat A = NULL;
+	const PetscScalar *vals = NULL;
 };
 
 // side table: operator -> arrays this glue allocated for it (they must outlive the operator)
@@ -47,6 +56,48 @@ void release_local_matrix(void *op)
 		g_local_matrices.erase(it);
 	}
 }
+LocalMatrix *local_matrix_of(void *op)
+{
+	auto it = g_local_matrices.find(op);
+	return it == g_local_matrices.end() ? nullptr : it->second;
+}
+
+/// The value array of the rank-local matrix, through the accessor of its type
+PetscErrorCode get_values(Mat A, const int bs, const PetscScalar **vals)
+{
+	PetscErrorCode ierr = 0;
+	if (bs == 1) {
+		ierr = MatSeqAIJGetArrayRead(A, vals); CHKERRQ(ierr);
+	} else {
+		PetscScalar *v = NULL;
+		ierr = MatSeqBAIJGetArray(A, &v); CHKERRQ(ierr);
+		*vals = v;
+	}
+	return ierr;
+}
+PetscErrorCode restore_values(Mat A, const int bs, const PetscScalar **vals)
+{
+	PetscErrorCode ierr = 0;
+	if (bs == 1) {
+		ierr = MatSeqAIJRestoreArrayRead(A, vals); CHKERRQ(ierr);
+	} else {
+		PetscScalar *v = const_cast<PetscScalar *>(*vals);
+		ierr = MatSeqBAIJRestoreArray(A, &v); CHKERRQ(ierr);
+		*vals = NULL;
+	}
+	return ierr;
+}
+
+#if defined(PETSC_HAVE_HIP)
+/// true when the vector's entries live in HBM (any of PETSc's HIP vector types)
+bool vec_is_hip(Vec v)
+{
+	VecType t = NULL;
+	if (VecGetType(v, &t) || !t)
+		return false;
+	return std::strcmp(t, VECSEQHIP) == 0 || std::strcmp(t, VECHIP) == 0 || std::strcmp(t, "mpihip") == 0;
+}
+#endif
 
 struct StopWatch {
 	std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
@@ -193,6 +244,7 @@ PetscErrorCode create_operator(PC pc)
 {
 	Blasted_data *ctx;
 	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
+	release_local_matrix(ctx->bprec);
 	delete reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
 	ctx->bprec = nullptr;
 
@@ -230,30 +282,35 @@ PetscErrorCode create_operator(PC pc)
 	if (ctx->bs <= 0 || ctx->bs == 6 || ctx->bs > 8)
 		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "BLASTed: this block size is not supported!");
 
-	// block-row structure and values through the public interface
+	// (block-)row structure through the public interface: copied (integers, once per operator) and handed
+	// back at once, so that nothing of the Mat is held between calls
+	const PetscBool compressed = ctx->bs > 1 ? PETSC_TRUE : PETSC_FALSE;
 	PetscInt nbr = 0;
 	const PetscInt *ia = NULL, *ja = NULL;
 	PetscBool done = PETSC_FALSE;
-	ierr = MatGetRowIJ(A, 0, PETSC_FALSE, ctx->bs > 1 ? PETSC_TRUE : PETSC_FALSE, &nbr, &ia, &ja, &done);
-	CHKERRQ(ierr);
-	if (!done || nbr != localrows / ctx->bs)
+	ierr = MatGetRowIJ(A, 0, PETSC_FALSE, compressed, &nbr, &ia, &ja, &done); CHKERRQ(ierr);
+	if (!done || nbr != localrows / ctx->bs) {
+		if (done)
+			MatRestoreRowIJ(A, 0, PETSC_FALSE, compressed, &nbr, &ia, &ja, &done);
 		SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "BLASTed: could not access the (block-)row structure");
-	const PetscScalar *vals = NULL;
-	if (ctx->bs == 1) {
-		ierr = MatSeqAIJGetArrayRead(A, &vals); CHKERRQ(ierr);
-	} else {
-		PetscScalar *v = NULL;
-		ierr = MatSeqBAIJGetArray(A, &v); CHKERRQ(ierr);
-		vals = v;
 	}
-
-	// diagonal positions (integer scan, once per pattern); the vector lives as long as the operator
 	LocalMatrix *lm = new LocalMatrix;
+	lm->A = A;
+	lm->ia.assign(ia, ia + nbr + 1);
+	lm->ja.assign(ja, ja + ia[nbr]);
+	ierr = MatRestoreRowIJ(A, 0, PETSC_FALSE, compressed, &nbr, &ia, &ja, &done);
+	if (ierr) {
+		delete lm;
+		return ierr;
+	}
+	nbr = (PetscInt)lm->ia.size() - 1;
+
+	// diagonal positions (integer scan, once per pattern)
 	lm->diag.resize(nbr);
 	for (PetscInt i = 0; i < nbr; i++) {
 		PetscInt d = -1;
-		for (PetscInt j = ia[i]; j < ia[i + 1]; j++)
-			if (ja[j] == i) {
+		for (PetscInt j = lm->ia[i]; j < lm->ia[i + 1]; j++)
+			if (lm->ja[j] == i) {
 				d = j;
 				break;
 			}
@@ -264,10 +321,31 @@ PetscErrorCode create_operator(PC pc)
 		lm->diag[i] = d;
 	}
 
-	BlastedPreconditioner *precop = factory->create_preconditioner(
-	    SRMatrixStorage<const PetscReal, const PetscInt>(ia, ja, vals, lm->diag.data(), ia + 1, nbr, ia[nbr],
-	                                                     ia[nbr], ctx->bs),
-	    settings);
+	// the operator wraps the Mat's value array, zero copy on the host side, and reads it in compute() only
+	// (compute_preconditioner_blasted takes it out again around that call and checks that it has not moved)
+	ierr = get_values(A, ctx->bs, &lm->vals);
+	if (ierr) {
+		delete lm;
+		return ierr;
+	}
+	const PetscScalar *vals = lm->vals;
+	const PetscScalar *held = vals;
+	ierr = restore_values(A, ctx->bs, &held);
+	if (ierr) {
+		delete lm;
+		return ierr;
+	}
+
+	BlastedPreconditioner *precop = NULL;
+	try {
+		precop = factory->create_preconditioner(
+		    SRMatrixStorage<const PetscReal, const PetscInt>(lm->ia.data(), lm->ja.data(), vals, lm->diag.data(),
+		                                                     lm->ia.data() + 1, nbr, lm->ia[nbr], lm->ia[nbr], ctx->bs),
+		    settings);
+	} catch (...) {
+		delete lm;
+		throw;
+	}
 	ctx->bprec = reinterpret_cast<void *>(precop);
 	register_local_matrix(ctx->bprec, lm);  // released in cleanup_blasted together with the operator
 
@@ -350,12 +428,27 @@ PetscErrorCode compute_preconditioner_blasted(PC pc)
 		ierr = read_options(pc); CHKERRQ(ierr);
 		ierr = create_operator(pc); CHKERRQ(ierr);
 	}
-	const StopWatch sw;
-	BlastedPreconditioner *const precop = reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
-	const PrecInfo pinfo = precop->compute();  // values H2D + factorisation on the GPU
-	if (ctx->compute_precinfo)
-		static_cast<PrecInfoList *>(ctx->infolist)->infolist.push_back(pinfo);
-	sw.add_to(ctx->factorwalltime, ctx->factorcputime);
+	// the operator reads the Mat's values now: take the array out for the duration of the call.  A new Mat,
+	// or an array that has moved since the operator was created, gets a new operator.
+	Mat A;
+	ierr = PCGetOperators(pc, NULL, &A); CHKERRQ(ierr);
+	LocalMatrix *lm = local_matrix_of(ctx->bprec);
+	const PetscScalar *vals = NULL;
+	ierr = get_values(A, ctx->bs, &vals); CHKERRQ(ierr);
+	if (!lm || lm->A != A || lm->vals != vals) {
+		ierr = restore_values(A, ctx->bs, &vals); CHKERRQ(ierr);
+		ierr = create_operator(pc); CHKERRQ(ierr);
+		ierr = get_values(A, ctx->bs, &vals); CHKERRQ(ierr);
+	}
+	{
+		const StopWatch sw;
+		BlastedPreconditioner *const precop = reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+		const PrecInfo pinfo = precop->compute();  // values H2D + factorisation on the GPU
+		if (ctx->compute_precinfo)
+			static_cast<PrecInfoList *>(ctx->infolist)->infolist.push_back(pinfo);
+		sw.add_to(ctx->factorwalltime, ctx->factorcputime);
+	}
+	ierr = restore_values(A, ctx->bs, &vals); CHKERRQ(ierr);
 	return ierr;
 }
 
@@ -364,6 +457,26 @@ PetscErrorCode apply_local_blasted(PC pc, Vec r, Vec z)
 	Blasted_data *ctx;
 	PetscErrorCode ierr = PCShellGetContext(pc, (void **)&ctx); CHKERRQ(ierr);
 	const BlastedPreconditioner *const prec = reinterpret_cast<const BlastedPreconditioner *>(ctx->bprec);
+#if defined(PETSC_HAVE_HIP)
+	if (vec_is_hip(r) && vec_is_hip(z) && prec->deviceVectorsAvailable()) {
+		// both vectors live in HBM: the operator works on them in place.  PETSc's own kernels may run on any
+		// stream and the operator has a private one, so the device is drained on either side of the call.
+		const PetscReal *rd;
+		PetscReal *zd;
+		ierr = VecHIPGetArrayRead(r, &rd); CHKERRQ(ierr);
+		ierr = VecHIPGetArrayWrite(z, &zd); CHKERRQ(ierr);
+		{
+			const StopWatch sw;
+			blasted::detail::device_synchronize();
+			prec->apply_device(rd, zd);
+			blasted::detail::device_synchronize();
+			sw.add_to(ctx->applywalltime, ctx->applycputime);
+		}
+		ierr = VecHIPRestoreArrayWrite(z, &zd); CHKERRQ(ierr);
+		ierr = VecHIPRestoreArrayRead(r, &rd); CHKERRQ(ierr);
+		return ierr;
+	}
+#endif
 	const PetscReal *ra;
 	PetscReal *za;
 	ierr = VecGetArray(z, &za); CHKERRQ(ierr);
@@ -390,6 +503,26 @@ PetscErrorCode relax_local_blasted(PC pc, Vec rhs, Vec x, Vec w, const PetscReal
 	if (guesszero) {
 		ierr = VecSet(x, 0.0); CHKERRQ(ierr);
 	}
+#if defined(PETSC_HAVE_HIP)
+	if (vec_is_hip(rhs) && vec_is_hip(x) && relaxation->deviceVectorsAvailable()) {
+		const PetscReal *bd;
+		PetscReal *xd;
+		ierr = VecHIPGetArrayRead(rhs, &bd); CHKERRQ(ierr);
+		ierr = VecHIPGetArray(x, &xd); CHKERRQ(ierr);  // initial guess and result
+		{
+			const StopWatch sw;
+			blasted::detail::device_synchronize();
+			relaxation->apply_relax_device(bd, xd);
+			blasted::detail::device_synchronize();
+			sw.add_to(ctx->applywalltime, ctx->applycputime);
+		}
+		ierr = VecHIPRestoreArray(x, &xd); CHKERRQ(ierr);
+		ierr = VecHIPRestoreArrayRead(rhs, &bd); CHKERRQ(ierr);
+		*reason = PCRICHARDSON_CONVERGED_ITS;
+		*outits = it;
+		return ierr;
+	}
+#endif
 	const PetscReal *ba;
 	PetscReal *xa;
 	ierr = VecGetArray(x, &xa); CHKERRQ(ierr);

@@ -1,8 +1,10 @@
-// mmio.cpp -- Matrix-Market input and COO -> CSR/BSR conversion (see blasted/mmio.hpp for the reference
+// mmio.cpp -- Matrix-Market / PETSc-binary input and COO -> CSR/BSR conversion (see blasted/mmio.hpp for the reference
 // surface this provides and the deliberate differences).
 #include "blasted/mmio.hpp"
 
 #include <algorithm>
+#include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -186,6 +188,12 @@ void COOMatrix<scalar, index>::readMatrixMarket(const std::string file)
 		entries[(size_t)k] = {(index)(ri - 1), (index)(ci - 1), v};  // the file is 1-based
 	}
 
+	sortEntries();
+}
+
+template <typename scalar, typename index>
+void COOMatrix<scalar, index>::sortEntries()
+{
 	// by row, then by column; equal positions keep their file order
 	std::stable_sort(entries.begin(), entries.end(), [](const Entry<scalar, index> &a, const Entry<scalar, index> &b) {
 		return a.rowind != b.rowind ? a.rowind < b.rowind : a.colind < b.colind;
@@ -195,6 +203,115 @@ void COOMatrix<scalar, index>::readMatrixMarket(const std::string file)
 		rowptr[(size_t)e.rowind + 1]++;
 	for (index i = 0; i < nrows; i++)
 		rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+}
+
+namespace {
+
+constexpr long PETSC_MAT_CLASSID = 1211216, PETSC_VEC_CLASSID = 1211214;
+
+std::vector<unsigned char> read_whole_file(const std::string &file)
+{
+	std::ifstream fin(file, std::ios::binary | std::ios::ate);
+	if (!fin)
+		throw MatrixReadException(file + ": could not be opened to read");
+	const std::streamsize size = fin.tellg();
+	fin.seekg(0);
+	std::vector<unsigned char> raw((size_t)size);
+	if (size > 0 && !fin.read(reinterpret_cast<char *>(raw.data()), size))
+		throw MatrixReadException(file + ": read error");
+	return raw;
+}
+
+// PETSc binary files are big-endian whatever the host
+long be_int32(const unsigned char *p)
+{
+	const uint32_t u = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+	return (long)(int32_t)u;
+}
+
+double be_float64(const unsigned char *p)
+{
+	uint64_t u = 0;
+	for (int i = 0; i < 8; i++)
+		u = (u << 8) | p[i];
+	double d;
+	std::memcpy(&d, &u, sizeof d);
+	return d;
+}
+
+}  // namespace
+
+template <typename scalar, typename index>
+void COOMatrix<scalar, index>::readPetscBinary(const std::string file)
+{
+	const std::vector<unsigned char> raw = read_whole_file(file);
+	if (raw.size() < 16 || be_int32(&raw[0]) != PETSC_MAT_CLASSID)
+		throw MatrixReadException(file + ": not a PETSc binary matrix");
+	const long nr = be_int32(&raw[4]), nc = be_int32(&raw[8]), nz = be_int32(&raw[12]);
+	if (nz < 0)
+		throw MatrixReadException(file + ": dense PETSc binary matrices are not supported");
+	if (nr < 0 || nc < 0)
+		throw MatrixReadException(file + ": negative size");
+	if (raw.size() != 16 + 4 * (size_t)nr + 12 * (size_t)nz)
+		throw MatrixReadException(file + ": inconsistent PETSc binary matrix (file size)");
+	nrows = checked_index<index>(nr, file);
+	ncols = checked_index<index>(nc, file);
+	nnz = checked_index<index>(nz, file);
+	const unsigned char *const lens = &raw[16], *const cols = lens + 4 * (size_t)nr,
+	                           *const vals = cols + 4 * (size_t)nz;
+	entries.resize((size_t)nnz);
+	size_t k = 0;
+	for (long i = 0; i < nr; i++) {
+		const long len = be_int32(lens + 4 * i);
+		if (len < 0 || k + (size_t)len > (size_t)nz)
+			throw MatrixReadException(file + ": inconsistent PETSc binary matrix (row lengths)");
+		for (long q = 0; q < len; q++, k++) {
+			const long ci = be_int32(cols + 4 * k);
+			if (ci < 0 || ci >= nc)
+				throw MatrixReadException(file + ": entry outside the matrix");
+			entries[k] = {(index)i, (index)ci, (scalar)be_float64(vals + 8 * k)};
+		}
+	}
+	if (k != (size_t)nz)
+		throw MatrixReadException(file + ": inconsistent PETSc binary matrix (row lengths)");
+	sortEntries();
+}
+
+template <typename scalar>
+device_vector<scalar> readPetscBinaryVector(const std::string file)
+{
+	const std::vector<unsigned char> raw = read_whole_file(file);
+	if (raw.size() < 8 || be_int32(&raw[0]) != PETSC_VEC_CLASSID)
+		throw MatrixReadException(file + ": not a PETSc binary vector");
+	const long n = be_int32(&raw[4]);
+	if (n < 0 || raw.size() != 8 + 8 * (size_t)n)
+		throw MatrixReadException(file + ": inconsistent PETSc binary vector");
+	device_vector<scalar> v((size_t)n);
+	for (long i = 0; i < n; i++)
+		v[(size_t)i] = (scalar)be_float64(&raw[8 + 8 * (size_t)i]);
+	return v;
+}
+
+template device_vector<double> readPetscBinaryVector<double>(const std::string file);
+template device_vector<float> readPetscBinaryVector<float>(const std::string file);
+
+int petscBinaryBlockSize(const std::string file)
+{
+	std::ifstream fin(file + ".info");
+	int bs = 1;
+	for (std::string line; fin && std::getline(fin, line);) {
+		const std::vector<std::string> w = words(line);
+		if (w.size() == 2 && w[0] == "-matload_block_size") {
+			try {
+				bs = std::stoi(w[1]);
+			} catch (const std::exception &) {
+				throw MatrixReadException(file + ".info: invalid -matload_block_size");
+			}
+		}
+	}
+	if (bs < 1)
+		throw MatrixReadException(file + ".info: invalid -matload_block_size");
+	return bs;
 }
 
 template <typename scalar, typename index>

@@ -11,10 +11,11 @@
 
 namespace blasted {
 
+// the reference's column titles and width (src/solverfactory.cpp:19-22): reports line up with its own
 const std::array<std::string, 6> PrecInfoList::descr = {
-    {"ILU-remainder", "Initial-ILU-rem", "Upper-min-diag-dom", "Upper-avg-diag-dom", "Lower-min-diag-dom",
-     "Lower-avg-diag-dom"}};
-const int PrecInfoList::field_width = 20;
+    {"factor_remainder", "factor_init_rem", "upperF_min_dgdom", "upperF_avg_dgdom", "lowerF_min_dgdom",
+     "lowerF_avg_dgdom"}};
+const int PrecInfoList::field_width = 18;
 
 namespace detail {
 
@@ -78,6 +79,15 @@ HipOperator::~HipOperator()
 void HipOperator::bind(const CRawBSRMatrix<double, int> &mat, const int bs, const StorageOptions stor)
 {
 	if (!pattern_set) {
+		// the device mirror is a compact BSR: a row ends where the next one starts.  A view whose browendptr
+		// says otherwise (rows with unused tail storage, which the reference's kernels would honour) or whose
+		// nnzb disagrees with browptr is refused instead of silently misread.
+		if (mat.nnzb != mat.browptr[mat.nbrows] - mat.browptr[0] || mat.browptr[0] != 0)
+			throw std::invalid_argument("BLASTed(HIP): nnzb does not match browptr");
+		if (mat.browendptr && mat.browendptr != mat.browptr + 1)
+			for (int i = 0; i < mat.nbrows; i++)
+				if (mat.browendptr[i] != mat.browptr[i + 1])
+					throw std::invalid_argument("BLASTed(HIP): browendptr[i] != browptr[i+1] (padded rows are not supported)");
 		check(blasted_hip_set_pattern(h, mat.nbrows, mat.browptr[mat.nbrows], bs,
 		                              stor == RowMajor ? BLASTED_HIP_ROWMAJOR : BLASTED_HIP_COLMAJOR,
 		                              mat.browptr, mat.bcolind, mat.diagind, BLASTED_HIP_HOST));
@@ -103,6 +113,10 @@ void device_buffer_upload(void *dev, const void *host, const std::size_t nbytes)
 void device_buffer_download(void *host, const void *dev, const std::size_t nbytes)
 {
 	HipOperator::check(blasted_hip_buffer_download(host, dev, nbytes));
+}
+void device_synchronize()
+{
+	HipOperator::check(blasted_hip_device_synchronize(HipOperator::default_device()));
 }
 
 }  // namespace detail
@@ -165,15 +179,15 @@ SRPreconditioner<scalar, index>::~SRPreconditioner()
 }
 
 template <typename scalar, typename index>
-void SRPreconditioner<scalar, index>::apply_device(const scalar *const, scalar *const) const
+void SRPreconditioner<scalar, index>::apply_at(const scalar *const, scalar *const, const int) const
 {
-	throw std::runtime_error("apply_device is not provided by this operator");
+	throw std::runtime_error("apply on device vectors is not provided by this operator");
 }
 
 template <typename scalar, typename index>
-void SRPreconditioner<scalar, index>::apply_relax_device(const scalar *const, scalar *const) const
+void SRPreconditioner<scalar, index>::relax_at(const scalar *const, scalar *const, const int) const
 {
-	throw std::runtime_error("apply_relax_device is not provided by this operator");
+	throw std::runtime_error("relaxation on device vectors is not provided by this operator");
 }
 
 template <typename scalar, typename index>
@@ -231,29 +245,33 @@ template <typename scalar, typename index, int bs, StorageOptions stor>
 void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
                                                              scalar *const __restrict z) const
 {
-	if (!op)
-		throw std::runtime_error("Jacobi preconditioner: apply() before compute()");
-	HipOperator::check(blasted_hip_jacobi_apply(op->get(), r, z, BLASTED_HIP_HOST));
+	this->apply_at(r, z, BLASTED_HIP_HOST);
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
-void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
-                                                                    scalar *const dz) const
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_at(const scalar *const r, scalar *const z,
+                                                                const int loc) const
 {
 	if (!op)
 		throw std::runtime_error("Jacobi preconditioner: apply() before compute()");
-	HipOperator::check(blasted_hip_jacobi_apply(op->get(), dr, dz, BLASTED_HIP_DEVICE));
+	HipOperator::check(blasted_hip_jacobi_apply(op->get(), r, z, loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void BJacobiSRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const b,
                                                                    scalar *const __restrict x) const
 {
+	this->relax_at(b, x, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void BJacobiSRPreconditioner<scalar, index, bs, stor>::relax_at(const scalar *const b, scalar *const x,
+                                                                const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("Jacobi preconditioner: apply_relax() before compute()");
 	HipOperator::check(blasted_hip_jacobi_relax(op->get(), b, x, solveparams.maxits, solveparams.ctol ? 1 : 0,
-	                                            solveparams.rtol, solveparams.atol, solveparams.dtol, nullptr,
-	                                            BLASTED_HIP_HOST));
+	                                            solveparams.rtol, solveparams.atol, solveparams.dtol, nullptr, loc));
 }
 
 // ------------------------------------------------------------------------------- (block-)SGS
@@ -283,41 +301,35 @@ template <typename scalar, typename index, int bs, StorageOptions stor>
 void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
                                                                     scalar *const __restrict z) const
 {
-	if (!op)
-		throw std::runtime_error("SGS preconditioner: apply() before compute()");
-	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, napplysweeps, (int)ainit,
-	                                         HipOperator::sweep_mode(), BLASTED_HIP_HOST));
+	this->apply_at(r, z, BLASTED_HIP_HOST);
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
-void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
-                                                                           scalar *const dz) const
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_at(const scalar *const r, scalar *const z,
+                                                                       const int loc) const
 {
 	if (!op)
 		throw std::runtime_error("SGS preconditioner: apply() before compute()");
-	HipOperator::check(blasted_hip_sgs_apply(op->get(), dr, dz, napplysweeps, (int)ainit,
-	                                         HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, napplysweeps, (int)ainit,
+	                                         HipOperator::sweep_mode(), loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const b,
                                                                           scalar *const __restrict x) const
 {
+	this->relax_at(b, x, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::relax_at(const scalar *const b, scalar *const x,
+                                                                       const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
 	// maxits steps; tolerances are never checked for SGS (src/solverops_sgs.cpp:96-115)
 	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, detail::async_or_sync_mode(),
-	                                         BLASTED_HIP_HOST));
-}
-
-template <typename scalar, typename index, int bs, StorageOptions stor>
-void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_relax_device(const scalar *const db,
-                                                                                 scalar *const dx) const
-{
-	if (!op)
-		throw std::runtime_error("SGS relaxation: apply_relax() before compute()");
-	HipOperator::check(blasted_hip_sgs_relax(op->get(), db, dx, solveparams.maxits,
-	                                         detail::async_or_sync_mode(), BLASTED_HIP_DEVICE));
+	                                         loc));
 }
 
 // ------------------------------------------------------------------------------- chaotic relaxation (gs)
@@ -334,20 +346,32 @@ template <typename scalar, typename index, int bs, StorageOptions stor>
 void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply(const scalar *const b,
                                                             scalar *const __restrict x) const
 {
+	this->apply_at(b, x, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply_at(const scalar *const b, scalar *const x,
+                                                               const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("chaotic relaxation: apply() before compute()");
-	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, napplysweeps, detail::async_or_sync_mode(),
-	                                        BLASTED_HIP_HOST));
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, napplysweeps, detail::async_or_sync_mode(), loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void ChaoticBlockRelaxation<scalar, index, bs, stor>::apply_relax(const scalar *const b,
                                                                   scalar *const __restrict x) const
 {
+	this->relax_at(b, x, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void ChaoticBlockRelaxation<scalar, index, bs, stor>::relax_at(const scalar *const b, scalar *const x,
+                                                               const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("chaotic relaxation: apply_relax() before compute()");
-	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, solveparams.maxits, detail::async_or_sync_mode(),
-	                                        BLASTED_HIP_HOST));
+	HipOperator::check(blasted_hip_gs_relax(op->get(), b, x, solveparams.maxits, detail::async_or_sync_mode(), loc));
 }
 
 // ------------------------------------------------------------------------------- (block-)ILU(0)
@@ -387,31 +411,32 @@ template <typename scalar, typename index, int bs, StorageOptions stor>
 void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply(const scalar *const r,
                                                                      scalar *const __restrict z) const
 {
+	this->apply_at(r, z, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_at(const scalar *const r, scalar *const z,
+                                                                        const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("ILU0 preconditioner: apply() before compute()");
 	if (applyinittype != INIT_A_ZERO && applyinittype != INIT_A_JACOBI)
 		throw std::runtime_error(" scalar_ilu0_apply: Invalid init type!");  // src/solverops_ilu0.cpp:125-126
 	const int sweeps = threadedapply ? napplysweeps : BLASTED_SEQUENTIAL_SYMBOL;
 	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, sweeps, (int)applyinittype,
-	                                          HipOperator::sweep_mode(), BLASTED_HIP_HOST));
-}
-
-template <typename scalar, typename index, int bs, StorageOptions stor>
-void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_device(const scalar *const dr,
-                                                                            scalar *const dz) const
-{
-	if (!op)
-		throw std::runtime_error("ILU0 preconditioner: apply() before compute()");
-	if (applyinittype != INIT_A_ZERO && applyinittype != INIT_A_JACOBI)
-		throw std::runtime_error(" scalar_ilu0_apply: Invalid init type!");
-	const int sweeps = threadedapply ? napplysweeps : BLASTED_SEQUENTIAL_SYMBOL;
-	HipOperator::check(blasted_hip_ilu0_apply(op->get(), dr, dz, sweeps, (int)applyinittype,
-	                                          HipOperator::sweep_mode(), BLASTED_HIP_DEVICE));
+	                                          HipOperator::sweep_mode(), loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_relax(const scalar *const,
                                                                            scalar *const __restrict) const
+{
+	throw std::runtime_error("ILU relaxation not implemented!");
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::relax_at(const scalar *const, scalar *const,
+                                                                        const int) const
 {
 	throw std::runtime_error("ILU relaxation not implemented!");
 }
@@ -437,22 +462,32 @@ PrecInfo Level_BSGS<scalar, index, bs, stor>::compute()
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void Level_BSGS<scalar, index, bs, stor>::apply(const scalar *const r, scalar *const __restrict z) const
 {
+	this->apply_at(r, z, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Level_BSGS<scalar, index, bs, stor>::apply_at(const scalar *const r, scalar *const z, const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("level SGS: apply() before compute()");
 	// one exact forward and one exact backward pass: no initial guess is read (the reference does not
 	// initialise y or z either), so the init type only has to avoid an upload of z
-	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
-	                                         BLASTED_HIP_HOST));
+	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL, loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
 void Level_BSGS<scalar, index, bs, stor>::apply_relax(const scalar *const b,
                                                       scalar *const __restrict x) const
 {
+	this->relax_at(b, x, BLASTED_HIP_HOST);
+}
+
+template <typename scalar, typename index, int bs, StorageOptions stor>
+void Level_BSGS<scalar, index, bs, stor>::relax_at(const scalar *const b, scalar *const x, const int loc) const
+{
 	if (!op)
 		throw std::runtime_error("level SGS: apply_relax() before compute()");
-	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, BLASTED_HIP_LEVEL,
-	                                         BLASTED_HIP_HOST));
+	HipOperator::check(blasted_hip_sgs_relax(op->get(), b, x, solveparams.maxits, BLASTED_HIP_LEVEL, loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
@@ -488,21 +523,17 @@ template <typename scalar, typename index, int bs, StorageOptions stor>
 void Async_Level_BlockILU0<scalar, index, bs, stor>::apply(const scalar *const r,
                                                            scalar *const __restrict z) const
 {
-	if (!op)
-		throw std::runtime_error("level ILU0: apply() before compute()");
-	// exact solves do not read an initial guess: the init type of the C ABI is irrelevant here
-	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
-	                                          BLASTED_HIP_HOST));
+	this->apply_at(r, z, BLASTED_HIP_HOST);
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
-void Async_Level_BlockILU0<scalar, index, bs, stor>::apply_device(const scalar *const dr,
-                                                                  scalar *const dz) const
+void Async_Level_BlockILU0<scalar, index, bs, stor>::apply_at(const scalar *const r, scalar *const z,
+                                                              const int loc) const
 {
 	if (!op)
 		throw std::runtime_error("level ILU0: apply() before compute()");
-	HipOperator::check(blasted_hip_ilu0_apply(op->get(), dr, dz, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL,
-	                                          BLASTED_HIP_DEVICE));
+	// exact solves do not read an initial guess: the init type of the C ABI is irrelevant here
+	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, 1, BLASTED_HIP_INIT_A_ZERO, BLASTED_HIP_LEVEL, loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>

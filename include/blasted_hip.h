@@ -69,6 +69,10 @@ int blasted_hip_device_count(void);
 int blasted_hip_create(blasted_hip_prec *out, int device, void *stream, int own_stream);
 int blasted_hip_destroy(blasted_hip_prec p);
 int blasted_hip_synchronize(blasted_hip_prec p);
+/* hipDeviceSynchronize on `device`: waits for every stream, the operators' private ones and any other
+ * library's.  For callers that hand over device vectors produced on streams this library does not know
+ * (the PCSHELL glue on PETSc's HIP vectors). */
+int blasted_hip_device_synchronize(int device);
 
 /* Sparsity pattern, once per object.  Validates sorted columns and the diagonal positions.
  * bs: 1 (scalar CSR semantics of AsyncILU0/AsyncSGS/Jacobi) or one of the instantiated block sizes.
@@ -146,6 +150,12 @@ int blasted_hip_level_count(blasted_hip_prec p, int *nlevels);
 /* out4 = { levels, fixed-point passes of the build, single-launch exact passes run so far, how many of
  * them gave up waiting and were redone with per-level launches (expected: 0) } */
 int blasted_hip_level_stats(blasted_hip_prec p, long *out4);
+/* HBM footprint: out4 = { bytes of device memory this operator holds now (pattern / value mirrors, factor,
+ * derived copies, vectors, schedules), the peak of that figure, how many derived two-triangle copies of the
+ * factor / matrix are resident (natural-order for the asynchronous sweeps, level-ordered for the exact
+ * solves; at most one per array unless tuning "copies=both"), bytes of caller-owned host memory this
+ * process has page-locked for staging (all operators) }.  Borrowed device arrays are not counted. */
+int blasted_hip_memory_stats(blasted_hip_prec p, long *out4);
 /* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
  * inside a level), level_ptr[nlevels+1] */
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr);
@@ -199,6 +209,9 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
  * factor's triangles (one more copy of the factor, one copy pass per factorisation) or the factor in
  * place (environment: BLASTED_HIP_COMPACT).
+ * "copies=one" (default) / "copies=both": keep only the derived copy last asked for, or both orderings
+ * (environment: BLASTED_HIP_COPIES=both).  "sgsfwd=exact" (default) / "sgsfwd=async": forward half of an
+ * ASYNC-mode SGS application as one exact pass (the reference's semantics) or as asynchronous sweeps.
  * "levelperm=0": the exact ILU solves keep natural-order vectors instead of a level-ordered iterate.
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
  * lets a wave of that kernel prefetch several row steps instead of one. */

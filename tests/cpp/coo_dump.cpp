@@ -1,4 +1,4 @@
-// Dumps what the host library's Matrix-Market route (coomatrix.hpp) makes of a file, for
+// Dumps what the host library's Matrix-Market / PETSc-binary (*.pmat) route (coomatrix.hpp) makes of a file, for
 // tests/test_host_build.py: "coo_dump <file.mtx> <bs> <rowmajor|colmajor> <out.bin>" writes
 // int32 nbrows, nnzb, then browptr[nbrows+1], bcolind[nnzb], diagind[nbrows] (int32) and vals (float64);
 // "coo_dump <file.mtx> dense <out.bin>" writes int64 count and the values.  Exit code 3 with the message on
@@ -40,7 +40,9 @@ int main(int argc, char **argv)
 	}
 	try {
 		if (std::strcmp(argv[2], "dense") == 0) {
-			const device_vector<double> v = readDenseMatrixMarket<double>(argv[1]);
+			const std::string path = argv[1];
+			const bool petsc = path.size() > 5 && path.compare(path.size() - 5, 5, ".pmat") == 0;
+			const device_vector<double> v = petsc ? readPetscBinaryVector<double>(path) : readDenseMatrixMarket<double>(path);
 			FILE *f = std::fopen(argv[3], "wb");
 			const long long n = (long long)v.size();
 			std::fwrite(&n, 8, 1, f);
@@ -48,9 +50,15 @@ int main(int argc, char **argv)
 			std::fclose(f);
 			return 0;
 		}
-		const int bs = std::atoi(argv[2]);
+		const std::string path = argv[1];
+		const bool petsc = path.size() > 5 && path.compare(path.size() - 5, 5, ".pmat") == 0;
+		// "info": the block size MatLoad would use, from <file>.info
+		const int bs = std::strcmp(argv[2], "info") == 0 ? petscBinaryBlockSize(path) : std::atoi(argv[2]);
 		COOMatrix<double, int> c;
-		c.readMatrixMarket(argv[1]);
+		if (petsc)
+			c.readPetscBinary(path);
+		else
+			c.readMatrixMarket(path);
 		switch (bs) {
 		case 1: return dump<1>(c, argv[3], argv[4]);
 		case 2: return dump<2>(c, argv[3], argv[4]);

@@ -1,0 +1,325 @@
+// petsc_driver.cpp -- TEST driver that executes the PCSHELL glue (blasted_amd/host/src/blasted_petsc.cpp)
+// the way a PETSc application does (the reference's tests/runpetsc.c + tests/testutils.cpp flow), on the
+// test-only mini-PETSc of tests/petsc_stub:
+//   options database  <-  the arguments after "--"           (-blasted_pc_type ilu0 -blasted_async_sweeps 3,3 ...)
+//   Mat (SeqAIJ or SeqBAIJ) from a Matrix-Market / PETSc-binary file, KSP + PC from -pc_type / -sub_pc_type
+//   setup_blasted_stack(ksp, &list)                           installs the callbacks in the PCSHELL it finds
+//   KSPSetUp                                                  -> compute_preconditioner_blasted
+//   PCApply(r) -> z, PCApplyRichardson(b) -> x                -> apply_local_blasted / relax_local_blasted
+//   values scaled in place, KSPSetOperators, KSPSetUp, PCApply -> the recompute path
+//   a right-preconditioned BiCGStab with PCApply as M^-1      (solve-level known answer, --b_file / --x_file)
+//   computeTotalTimes, KSPDestroy (-> cleanup_blasted), destroyBlastedDataList
+// Results go to <out>_*.bin (float64) and a key = value report on stdout that tests/test_gpu_petsc.py reads.
+//
+// usage: petsc_driver --mat_file F [--mat_type aij|baij] [--block_size N|0] [--vec_type seq|hip] [--out PREFIX]
+//                     [--b_file F --x_file F --solver_tol T --max_iter N] [--relax_its N] -- <-petsc_option value>...
+#undef NDEBUG
+#include <cassert>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "blasted_petsc.h"
+#include "coomatrix.hpp"
+
+using namespace blasted;
+
+#define CHK(call)                                                                   \
+	do {                                                                            \
+		const PetscErrorCode ierr_ = (call);                                        \
+		if (ierr_) {                                                                \
+			std::fprintf(stderr, "PETSc error %d in %s\n", (int)ierr_, #call);      \
+			std::exit(10 + (ierr_ % 100));                                          \
+		}                                                                           \
+	} while (0)
+
+static long petsc_classid(const std::string &path)
+{
+	std::ifstream f(path, std::ios::binary);
+	unsigned char h[4] = {0, 0, 0, 0};
+	f.read(reinterpret_cast<char *>(h), 4);
+	return f ? (long)(((unsigned)h[0] << 24) | ((unsigned)h[1] << 16) | ((unsigned)h[2] << 8) | h[3]) : -1;
+}
+
+static std::vector<double> read_vector(const std::string &path)
+{
+	const device_vector<double> v =
+	    petsc_classid(path) == 1211214 ? readPetscBinaryVector<double>(path) : readDenseMatrixMarket<double>(path);
+	return std::vector<double>(v.begin(), v.end());
+}
+
+template <int bs>
+static SRMatrixStorage<double, int> read_matrix(const std::string &path)
+{
+	COOMatrix<double, int> coo;
+	if (petsc_classid(path) == 1211216)
+		coo.readPetscBinary(path);
+	else
+		coo.readMatrixMarket(path);
+	return getSRMatrixFromCOO<double, int, bs>(coo, "colmajor");  // PETSc BAIJ blocks are column-major
+}
+
+static SRMatrixStorage<double, int> read_matrix_bs(const std::string &path, const int bs)
+{
+	switch (bs) {
+	case 1: return read_matrix<1>(path);
+	case 2: return read_matrix<2>(path);
+	case 3: return read_matrix<3>(path);
+	case 4: return read_matrix<4>(path);
+	case 5: return read_matrix<5>(path);
+	case 7: return read_matrix<7>(path);
+	case 8: return read_matrix<8>(path);
+	default: std::fprintf(stderr, "block size not built into the driver\n"); std::exit(2);
+	}
+}
+
+static void write_bin(const std::string &path, const std::vector<double> &v)
+{
+	FILE *f = std::fopen(path.c_str(), "wb");
+	assert(f);
+	std::fwrite(v.data(), sizeof(double), v.size(), f);
+	std::fclose(f);
+}
+
+static void set_vec(Vec v, const std::vector<double> &x)
+{
+	PetscScalar *a;
+	CHK(VecGetArray(v, &a));
+	std::memcpy(a, x.data(), sizeof(double) * x.size());
+	CHK(VecRestoreArray(v, &a));
+}
+
+static std::vector<double> get_vec(Vec v)
+{
+	PetscInt n;
+	CHK(VecGetLocalSize(v, &n));
+	const PetscScalar *a;
+	CHK(VecGetArrayRead(v, &a));
+	std::vector<double> x(a, a + n);
+	CHK(VecRestoreArrayRead(v, &a));
+	return x;
+}
+
+// host BSR product of the test harness (the "KSP" side of the solve; PETSc's MatMult in a real run)
+static void spmv(const SRMatrixStorage<double, int> &m, const int bs, const double scale, const std::vector<double> &x,
+                 std::vector<double> &y)
+{
+	std::fill(y.begin(), y.end(), 0.0);
+	for (int i = 0; i < m.nbrows; i++)
+		for (int j = m.browptr[i]; j < m.browptr[i + 1]; j++) {
+			const double *blk = &m.vals[(long)j * bs * bs];
+			const int col = m.bcolind[j];
+			for (int c = 0; c < bs; c++)
+				for (int r = 0; r < bs; r++)
+					y[(long)i * bs + r] += scale * blk[c * bs + r] * x[(long)col * bs + c];
+		}
+}
+
+static double dot(const std::vector<double> &a, const std::vector<double> &b)
+{
+	double s = 0;
+	for (size_t i = 0; i < a.size(); i++)
+		s += a[i] * b[i];
+	return s;
+}
+
+int main(int argc, char **argv)
+{
+	std::map<std::string, std::string> kv;
+	int i = 1;
+	for (; i + 1 < argc && std::strcmp(argv[i], "--") != 0; i += 2)
+		kv[argv[i]] = argv[i + 1];
+	if (i < argc && std::strcmp(argv[i], "--") == 0)
+		i++;
+	CHK(PetscOptionsClear(NULL));
+	for (; i < argc; i++) {
+		// "-name value" pairs; a name followed by another name (or nothing) is a flag
+		const std::string name = argv[i];
+		if (i + 1 < argc && !(argv[i + 1][0] == '-' && std::isalpha((unsigned char)argv[i + 1][1]))) {
+			CHK(PetscOptionsSetValue(NULL, name.c_str(), argv[i + 1]));
+			i++;
+		} else
+			CHK(PetscOptionsSetValue(NULL, name.c_str(), ""));
+	}
+	auto opt = [&](const char *k, const char *dflt) { return kv.count(k) ? kv[k] : std::string(dflt); };
+	const std::string matfile = opt("--mat_file", ""), mattype = opt("--mat_type", "baij"),
+	                  vectype = opt("--vec_type", "seq"), out = opt("--out", "/tmp/petsc_driver");
+	int bs = std::atoi(opt("--block_size", "0").c_str());
+	const int relax_its = std::atoi(opt("--relax_its", "3").c_str());
+	if (mattype == "aij")
+		bs = 1;
+	else if (bs <= 0)
+		bs = petscBinaryBlockSize(matfile);  // as MatLoad: -matload_block_size from <file>.info
+
+	try {
+		SRMatrixStorage<double, int> m = read_matrix_bs(matfile, bs);
+		const int n = m.nbrows * bs;
+		std::printf("matrix_rows = %d\nblock_size = %d\nnnzb = %d\n", n, bs, m.nnzb);
+
+		Mat A;
+		if (bs == 1)
+			CHK(MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, n, n, &m.browptr[0], &m.bcolind[0], &m.vals[0], &A));
+		else
+			CHK(MatCreateSeqBAIJWithArrays(PETSC_COMM_SELF, bs, n, n, &m.browptr[0], &m.bcolind[0], &m.vals[0], &A));
+
+		KSP ksp;
+		CHK(KSPCreate(PETSC_COMM_WORLD, &ksp));
+		CHK(KSPSetOperators(ksp, A, A));
+		CHK(KSPSetFromOptions(ksp));
+
+		Blasted_data_list bctx = newBlastedDataList();
+		CHK(setup_blasted_stack(ksp, &bctx));
+		std::printf("blasted_contexts = %d\n", bctx.size);
+		// what KSPSolve does first: KSPSetUp, then the inner solvers "on blocks" -- this is where PETSc calls
+		// the shell's set-up callback, i.e. compute_preconditioner_blasted, for the first time
+		CHK(KSPSetUp(ksp));
+		PC pc;
+		CHK(KSPGetPC(ksp, &pc));
+		CHK(PCSetUpOnBlocks(pc));
+		if (bctx.size > 0 && bctx.ctxlist->bprec == NULL) {
+			std::fprintf(stderr, "the shell was not set up\n");
+			return 5;
+		}
+
+		auto make_vec = [&](Vec *v) {
+			if (vectype == "hip")
+				CHK(VecCreateSeqHIP(PETSC_COMM_SELF, n, v));
+			else
+				CHK(VecCreateSeq(PETSC_COMM_SELF, n, v));
+		};
+		Vec r, z, w;
+		make_vec(&r);
+		make_vec(&z);
+		make_vec(&w);
+		std::vector<double> rhs(n);
+		for (int q = 0; q < n; q++)
+			rhs[q] = std::sin(0.37 * q) + 1.1;
+		set_vec(r, rhs);
+
+		// ---- apply
+		CHK(PCApply(pc, r, z));
+		write_bin(out + "_z.bin", get_vec(z));
+
+		// ---- relaxation (the types that register the Richardson callback)
+		PetscBool hasrich = PETSC_FALSE;
+		CHK(PCApplyRichardsonExists(pc, &hasrich));
+		std::printf("richardson_callback = %d\n", (int)hasrich);
+		if (hasrich) {
+			Vec x;
+			make_vec(&x);
+			set_vec(x, std::vector<double>(n, 123.0));  // guesszero must wipe this
+			PetscInt outits = -1;
+			PCRichardsonConvergedReason reason;
+			CHK(PCApplyRichardson(pc, r, x, w, 1e-5, 1e-50, 1e5, relax_its, PETSC_TRUE, &outits, &reason));
+			std::printf("richardson_its = %d\nrichardson_reason = %d\n", (int)outits, (int)reason);
+			write_bin(out + "_x.bin", get_vec(x));
+			CHK(VecDestroy(&x));
+		}
+
+		// ---- the matrix changes in place (a new time step): same pattern, values * 2, set up again
+		{
+			PetscScalar *a;
+			if (bs == 1)
+				CHK(MatSeqAIJGetArray(A, &a));
+			else
+				CHK(MatSeqBAIJGetArray(A, &a));
+			for (long q = 0; q < (long)m.nnzb * bs * bs; q++)
+				a[q] *= 2.0;
+			if (bs == 1)
+				CHK(MatSeqAIJRestoreArray(A, &a));
+			else
+				CHK(MatSeqBAIJRestoreArray(A, &a));
+		}
+		CHK(KSPSetOperators(ksp, A, A));
+		CHK(KSPSetUp(ksp));
+		CHK(PCSetUpOnBlocks(pc));
+		CHK(PCApply(pc, r, z));
+		write_bin(out + "_z2.bin", get_vec(z));
+
+		// ---- solve-level: right-preconditioned BiCGStab on the (doubled) system 2 A x = 2 b
+		if (kv.count("--b_file")) {
+			std::vector<double> b = read_vector(kv["--b_file"]);
+			for (double &v : b)
+				v *= 2.0;
+			const double tol = std::atof(opt("--solver_tol", "1e-10").c_str());
+			const int maxiter = std::atoi(opt("--max_iter", "200").c_str());
+			std::vector<double> x(n, 0.0), rr = b, rhat = b, p(n, 0.0), v(n, 0.0), y(n), zz(n), t(n);
+			double omega = 1, rhoold = 1, alpha = 1, resnorm = 1e300;
+			const double bnorm = std::sqrt(dot(b, b));
+			auto M = [&](const std::vector<double> &in, std::vector<double> &outv) {
+				set_vec(r, in);
+				CHK(PCApply(pc, r, z));
+				outv = get_vec(z);
+			};
+			int step = 0;
+			while (step < maxiter) {
+				const double rho = dot(rhat, rr);
+				const double beta = rho * alpha / (rhoold * omega);
+				for (int q = 0; q < n; q++)
+					p[q] = rr[q] + beta * p[q] - beta * omega * v[q];
+				M(p, y);
+				spmv(m, bs, 2.0, y, v);
+				alpha = rho / dot(rhat, v);
+				for (int q = 0; q < n; q++)
+					rr[q] -= alpha * v[q];
+				M(rr, zz);
+				spmv(m, bs, 2.0, zz, t);
+				omega = dot(t, rr) / dot(t, t);
+				for (int q = 0; q < n; q++) {
+					x[q] += alpha * y[q] + omega * zz[q];
+					rr[q] -= omega * t[q];
+				}
+				resnorm = std::sqrt(dot(rr, rr));
+				step++;
+				if (resnorm / bnorm < tol)
+					break;
+				rhoold = rho;
+			}
+			std::printf("solve_iterations = %d\nsolve_relres = %.6e\n", step, resnorm / bnorm);
+			if (kv.count("--x_file")) {
+				const std::vector<double> ans = read_vector(kv["--x_file"]);
+				double l2 = 0;
+				for (int q = 0; q < n; q++)
+					l2 += (x[q] - ans[q]) * (x[q] - ans[q]);
+				std::printf("solve_error_l2 = %.6e\n", std::sqrt(l2));
+			}
+		}
+
+		// ---- timers, names, info list, teardown
+		computeTotalTimes(&bctx);
+		std::printf("factor_walltime = %.6e\napply_walltime = %.6e\nfactor_cputime = %.6e\napply_cputime = %.6e\n",
+		            bctx.factorwalltime, bctx.applywalltime, bctx.factorcputime, bctx.applycputime);
+		for (Blasted_data *node = bctx.ctxlist; node; node = node->next) {
+			std::printf("node_prectype = %s\nnode_bs = %d\nnode_sweeps = %d,%d\n", node->prectypestr, node->bs,
+			            node->nbuildsweeps, node->napplysweeps);
+			if (node->infolist) {
+				const PrecInfoList *pl = static_cast<const PrecInfoList *>(node->infolist);
+				std::printf("precinfo_entries = %d\n", (int)pl->infolist.size());
+				for (size_t e = 0; e < pl->infolist.size(); e++)
+					for (int q = 0; q < 6; q++)
+						std::printf("precinfo_%zu_%s = %.12e\n", e, PrecInfoList::descr[q].c_str(),
+						            pl->infolist[e].f_info[q]);
+			}
+		}
+		std::printf("host_device_copies = %d\nhip_vector_accesses = %d\n", MiniPetscHostDeviceCopies(), MiniPetscHipAccesses());
+		CHK(VecDestroy(&r));
+		CHK(VecDestroy(&z));
+		CHK(VecDestroy(&w));
+		CHK(KSPDestroy(&ksp));  // -> cleanup_blasted
+		destroyBlastedDataList(&bctx);
+		CHK(MatDestroy(&A));
+		std::printf("outstanding_accesses = %d\n", MiniPetscOutstandingAccesses());
+		std::printf("done = 1\n");
+	} catch (const std::exception &e) {
+		std::fprintf(stderr, "exception: %s\n", e.what());
+		return 3;
+	}
+	return 0;
+}

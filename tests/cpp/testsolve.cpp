@@ -55,11 +55,21 @@ static Params parse(int argc, char **argv)
 	return p;
 }
 
-// Matrix Market input is the host library's (coomatrix.hpp), as in the reference's driver
-// (tests/testsolve.cpp:60-107)
+// PETSc binary files (the *.pmat fixtures the reference's PETSc drivers MatLoad / VecLoad) start with a
+// big-endian class id; anything else is taken as Matrix Market
+static long petsc_classid(const std::string &path)
+{
+	std::ifstream f(path, std::ios::binary);
+	unsigned char h[4] = {0, 0, 0, 0};
+	f.read(reinterpret_cast<char *>(h), 4);
+	return f ? (long)(((unsigned)h[0] << 24) | ((unsigned)h[1] << 16) | ((unsigned)h[2] << 8) | h[3]) : -1;
+}
+
+// Input is the host library's (coomatrix.hpp), as in the reference's driver (tests/testsolve.cpp:60-107)
 static std::vector<double> read_dense(const std::string &path)
 {
-	const device_vector<double> v = readDenseMatrixMarket<double>(path);
+	const device_vector<double> v =
+	    petsc_classid(path) == 1211214 ? readPetscBinaryVector<double>(path) : readDenseMatrixMarket<double>(path);
 	return std::vector<double>(v.begin(), v.end());
 }
 
@@ -67,7 +77,10 @@ template <int bs>
 static SRMatrixStorage<double, int> read_bsr(const std::string &path, const bool rowmajor)
 {
 	COOMatrix<double, int> coo;
-	coo.readMatrixMarket(path);
+	if (petsc_classid(path) == 1211216)
+		coo.readPetscBinary(path);
+	else
+		coo.readMatrixMarket(path);
 	return getSRMatrixFromCOO<double, int, bs>(coo, rowmajor ? "rowmajor" : "colmajor");
 }
 
@@ -196,7 +209,10 @@ int main(int argc, char **argv)
 	const Params p = parse(argc, argv);
 	try {
 		if (p.mattype == "csr") return test_solve<1>(p);
-		switch (p.blocksize) {
+		int blocksize = p.blocksize;
+		if (blocksize <= 0)  // --block_size 0: as MatLoad does, from <mat_file>.info (-matload_block_size)
+			blocksize = petscBinaryBlockSize(p.mat_file);
+		switch (blocksize) {
 		case 3: return test_solve<3>(p);
 		case 4: return test_solve<4>(p);
 		case 5: return test_solve<5>(p);

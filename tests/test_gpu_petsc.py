@@ -1,0 +1,221 @@
+"""GPU tests of the PCSHELL surface (SURVEY 8 rows b / f1): blasted_amd/host/src/blasted_petsc.cpp is built
+against the test-only mini-PETSc of tests/petsc_stub and EXECUTED by tests/cpp/petsc_driver.cpp the way a
+PETSc application runs it (the reference's tests/runpetsc.c flow): options database -> setup_blasted_stack
+-> KSPSetUp / set-up on blocks -> compute_preconditioner_blasted -> apply_local_blasted / relax_local_blasted
+-> a recompute on changed values -> computeTotalTimes -> cleanup_blasted, on the reference's 2dcyl1 matrix
+(PETSc binary, block size from its .info file) as SeqBAIJ and SeqAIJ, with host and with HIP-resident vectors.
+Results are compared with the CPU oracle at the same settings (reference: src/blasted_petsc.cpp:403-575,
+578-721)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from blasted_amd import mtxio, workloads as W
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "cpp", "build", "petsc_driver")
+G = os.path.join(ROOT, "tests", "golden")
+PMAT = os.path.join(G, "2dcyl1.pmat")
+
+ASYNC_OPTS = ["-blasted_async_fact_init_type", "init_original", "-blasted_async_apply_init_type", "init_zero",
+              "-blasted_thread_chunk_size", "128", "-blasted_use_symmetric_scaling", "0"]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def run(tmp_path, petsc_opts, mat_type="baij", vec_type="seq", pc=("bjacobi", "shell"), env=None, extra=(),
+        expect_rc=0):
+    out = str(tmp_path / "o")
+    tree = ["-pc_type", pc[0]] + (["-sub_pc_type", pc[1]] if pc[1] else [])
+    cmd = [DRIVER, "--mat_file", PMAT, "--mat_type", mat_type, "--vec_type", vec_type, "--out", out] + list(extra) + \
+          ["--"] + tree + list(petsc_opts)
+    e = dict(os.environ)
+    for k in ("BLASTED_HIP_SYNC_SWEEPS", "BLASTED_HIP_EXACT_APPLY"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == expect_rc, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = {}
+    for line in r.stdout.splitlines():
+        if " = " in line:
+            k, v = line.split(" = ", 1)
+            rep[k.strip()] = v.strip()
+    vecs = {}
+    for name in ("z", "x", "z2"):
+        f = out + "_%s.bin" % name
+        if os.path.exists(f):
+            vecs[name] = np.fromfile(f, np.float64)
+    return rep, vecs, r
+
+
+def matrix(mat_type):
+    return mtxio.read_petsc_bsr(PMAT, None if mat_type == "baij" else 1)
+
+
+def check_common(rep, vecs, bs, homogeneous=True):
+    assert rep["done"] == "1" and rep["blasted_contexts"] == "1"
+    assert rep["outstanding_accesses"] == "0"        # every Get... of the glue has its Restore...
+    assert int(rep["block_size"]) == bs and int(rep["node_bs"]) == bs
+    assert float(rep["factor_walltime"]) > 0 and float(rep["apply_walltime"]) > 0
+    # values * 2 in place, KSPSetOperators, set-up again: the operator of 2A applied to r is half that of A
+    # (not for a few factorisation sweeps from A itself as the initial guess: that iteration is not
+    # homogeneous in A -- those cases compare the second application with the oracle on 2A)
+    if homogeneous:
+        assert rel(vecs["z2"], 0.5 * vecs["z"]) < 1e-12
+
+
+def doubled(m):
+    m2 = dict(m)
+    m2["vals"] = 2.0 * m["vals"]
+    return m2
+
+
+SYNC = {"BLASTED_HIP_SYNC_SWEEPS": "1"}
+
+
+@pytest.mark.parametrize("mat_type,vec_type", [("baij", "seq"), ("aij", "seq"), ("baij", "hip"), ("aij", "hip")])
+def test_pcshell_ilu0_matches_oracle(tmp_path, mat_type, vec_type):
+    """-blasted_pc_type ilu0 -blasted_async_sweeps 3,3 with deterministic (synchronous) sweeps: factor and
+    apply equal the oracle's synchronous sweeps at the same counts; HIP vectors take the device branch."""
+    m = matrix(mat_type)
+    bs = m["bs"]
+    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS,
+                       mat_type, vec_type, env=SYNC)
+    check_common(rep, vecs, bs, homogeneous=False)
+    assert rep["node_prectype"] == "ilu0" and rep["node_sweeps"] == "3,3" and rep["richardson_callback"] == "0"
+    r = W.rhs_vector(m["nbrows"] * bs)
+    for mm, key in ((m, "z"), (doubled(m), "z2")):  # first set-up, and the set-up after the values changed
+        f = O.ilu0_factorize(mm, None, 3, mode=O.JACOBI_SYNC, init=O.INIT_F_ORIGINAL)["iluvals"]
+        want = O.ilu0_apply(mm, f, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)
+        assert rel(vecs[key], want) < 1e-12
+    if vec_type == "hip":
+        assert int(rep["hip_vector_accesses"]) >= 4   # r and z of two applies went through VecHIPGetArray...
+    else:
+        assert rep["hip_vector_accesses"] == "0"
+
+
+def test_pcshell_ilu0_scaled_with_info(tmp_path):
+    """symmetric scaling and -blasted_compute_preconditioner_info: one PrecInfo per compute(), remainder
+    below the initial remainder, values as the oracle's."""
+    m = matrix("aij")
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "4,3", "-blasted_async_fact_init_type", "init_original",
+            "-blasted_async_apply_init_type", "init_jacobi", "-blasted_thread_chunk_size", "64",
+            "-blasted_use_symmetric_scaling", "1", "-blasted_compute_preconditioner_info", "1"]
+    rep, vecs, _ = run(tmp_path, opts, "aij", env=SYNC)
+    check_common(rep, vecs, 1, homogeneous=False)
+    assert rep["precinfo_entries"] == "2"
+    r = W.rhs_vector(m["nbrows"])
+    fo = O.ilu0_factorize(m, None, 4, mode=O.JACOBI_SYNC, init=O.INIT_F_ORIGINAL, usescale=True, compute_info=True)
+    want = O.ilu0_apply(m, fo["iluvals"], r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_JACOBI, scale=fo["scale"])
+    assert rel(vecs["z"], want) < 1e-12
+    rem, rem0 = float(rep["precinfo_0_factor_remainder"]), float(rep["precinfo_0_factor_init_rem"])
+    assert 0 < rem < rem0
+    assert abs(rem - fo["precinfo"][0]) <= 1e-9 * fo["precinfo"][0]
+    assert abs(rem0 - fo["precinfo"][1]) <= 1e-9 * fo["precinfo"][1]
+
+
+@pytest.mark.parametrize("mat_type,vec_type", [("baij", "seq"), ("baij", "hip"), ("aij", "seq")])
+def test_pcshell_sgs_apply_and_richardson(tmp_path, mat_type, vec_type):
+    m = matrix(mat_type)
+    bs = m["bs"]
+    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,3"] + ASYNC_OPTS,
+                       mat_type, vec_type, env=SYNC, extra=["--relax_its", "4"])
+    check_common(rep, vecs, bs)
+    assert rep["richardson_callback"] == "1" and rep["richardson_its"] == "4"
+    assert rep["richardson_reason"] == "4"  # PCRICHARDSON_CONVERGED_ITS
+    r = W.rhs_vector(m["nbrows"] * bs)
+    d = O.jacobi_compute(m)
+    assert rel(vecs["z"], O.sgs_apply(m, d, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)) < 1e-12
+    # guesszero = TRUE: x starts from 0 whatever the vector held
+    assert rel(vecs["x"], O.sgs_relax(m, d, r, maxits=4, mode=O.JACOBI_SYNC)) < 1e-11
+
+
+def test_pcshell_sgs_product_mode_forward_half_exact(tmp_path):
+    """default (asynchronous) mode at the reference's low sweep count: z is no farther from the exact SGS
+    application than synchronous Jacobi backward sweeps from the exact forward solve (Q3)."""
+    m = matrix("baij")
+    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,2"] + ASYNC_OPTS)
+    check_common(rep, vecs, 4)
+    r = W.rhs_vector(m["nbrows"] * 4)
+    d = O.jacobi_compute(m)
+    ze, ye = O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL, return_y=True)
+    zj = O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=np.zeros_like(r))
+    assert np.linalg.norm(vecs["z"] - ze) <= 1.05 * np.linalg.norm(zj - ze) + 1e-12 * np.linalg.norm(ze)
+
+
+@pytest.mark.parametrize("opts,kind", [
+    (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "-1,-1"], "seqilu0"),
+    (["-blasted_pc_type", "seqilu0", "-blasted_async_sweeps", "1,1"], "seqilu0"),
+    (["-blasted_pc_type", "sapilu0", "-blasted_async_sweeps", "40,1"], "seqilu0"),
+    (["-blasted_pc_type", "async_level_ilu0", "-blasted_async_sweeps", "40,1"], "seqilu0"),
+    (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,40"], "seqilu0"),
+    (["-blasted_pc_type", "level_sgs"], "sgs"),
+    (["-blasted_pc_type", "jacobi"], "jacobi"),
+])
+def test_pcshell_exact_types(tmp_path, opts, kind):
+    """sequential / level-scheduled types, and asynchronous sweeps run to convergence, against the oracle's
+    serial result (the reference at OMP_NUM_THREADS=1)."""
+    m = matrix("baij")
+    needs = [] if opts[1] in ("level_sgs", "jacobi") else ASYNC_OPTS
+    rep, vecs, _ = run(tmp_path, opts + needs)
+    check_common(rep, vecs, 4)
+    r = W.rhs_vector(m["nbrows"] * 4)
+    if kind == "seqilu0":
+        f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+        want = O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)
+        tol = 1e-10
+    elif kind == "sgs":
+        want = O.sgs_apply(m, O.jacobi_compute(m), r, 1, mode=O.GS_SERIAL)
+        tol = 1e-12
+        assert rep["richardson_callback"] == "1"
+        assert rel(vecs["x"], O.sgs_relax(m, O.jacobi_compute(m), r, maxits=3, mode=O.GS_SERIAL)) < 1e-11
+    else:
+        d = O.jacobi_compute(m)
+        want = O.jacobi_apply(m, d, r)
+        tol = 1e-12
+        assert rel(vecs["x"], O.jacobi_relax(m, d, r, maxits=3)[0]) < 1e-11
+    assert rel(vecs["z"], want) < tol
+
+
+@pytest.mark.parametrize("pc", [("asm", "shell"), ("ksp", "shell"), ("shell", None)])
+def test_pcshell_tree_walk(tmp_path, pc):
+    """setup_blasted_stack finds the PCSHELL under asm / ksp containers and at the top level
+    (src/blasted_petsc.cpp:578-661)."""
+    m = matrix("baij")
+    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "seqilu0", "-blasted_async_sweeps", "1,1"] + ASYNC_OPTS, pc=pc)
+    check_common(rep, vecs, 4)
+    r = W.rhs_vector(m["nbrows"] * 4)
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(vecs["z"], O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)) < 1e-10
+
+
+@pytest.mark.parametrize("opts,vec_type", [
+    (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "10,15"], "seq"),     # ThreadedBSR4ILU0Colmajor's counts
+    (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "10,15"], "hip"),
+    (["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,15"], "seq"),
+    (["-blasted_pc_type", "sapilu0", "-blasted_async_sweeps", "12,1"], "hip"),
+])
+def test_pcshell_solve_known_answer(tmp_path, opts, vec_type):
+    """BiCGStab with PCApply as the preconditioner reaches the reference's shipped solution of 2dcyl1
+    (tests/CMakeLists.txt:159-173 through the PETSc route, tests/CMakeLists.txt:222-269)."""
+    rep, vecs, _ = run(tmp_path, opts + ASYNC_OPTS, vec_type=vec_type,
+                       extra=["--b_file", os.path.join(G, "2dcyl1_b.pmat"), "--x_file", os.path.join(G, "2dcyl1_x.pmat"),
+                              "--solver_tol", "1e-12", "--max_iter", "400"])
+    check_common(rep, vecs, 4, homogeneous=opts[1] == "sgs")
+    assert float(rep["solve_relres"]) < 1e-12 and float(rep["solve_error_l2"]) < 1e-8
+
+
+def test_pcshell_rejects_bad_options(tmp_path):
+    _, _, r = run(tmp_path, ["-blasted_pc_type", "bogus", "-blasted_async_sweeps", "1,1"] + ASYNC_OPTS, expect_rc=3)
+    assert "Preconditioner type not available" in r.stderr
+    # a PC tree without a shell: nothing to install, and the driver's first PCApply has no operator
+    out = subprocess.run([DRIVER, "--mat_file", PMAT, "--", "-pc_type", "bjacobi", "-sub_pc_type", "none",
+                          "-blasted_pc_type", "jacobi"], capture_output=True, text=True, timeout=120)
+    assert "blasted_contexts = 0" in out.stdout and out.returncode != 0

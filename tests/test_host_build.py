@@ -50,6 +50,31 @@ def test_pcshell_glue_typechecks_against_petsc_names():
                            os.path.join(HOST, "src", "blasted_petsc.cpp")])
 
 
+def test_pcshell_glue_also_compiles_without_hip_vectors():
+    """a PETSc configured without HIP has no VecHIP... names: the device branch must be compiled out"""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-UPETSC_HAVE_HIP",
+                           "-DBLASTED_TEST_NO_PETSC_HIP",
+                           "-I", os.path.join(ROOT, "tests", "petsc_stub"),
+                           "-I", os.path.join(HOST, "include"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(HOST, "src", "blasted_petsc.cpp")])
+
+
+def test_pcshell_driver_walks_the_tree_and_fails_loudly_without_gpu():
+    """the mini-PETSc driver gets as far as the first device call on a box without GPU: options are read, the
+    PCSHELL is found under bjacobi, the operator is created -- and compute() refuses to run on the CPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    drv = os.path.join(ROOT, "tests", "cpp", "build", "petsc_driver")
+    r = subprocess.run([drv, "--mat_file", os.path.join(ROOT, "tests", "golden", "2dcyl1.pmat"), "--",
+                        "-pc_type", "bjacobi", "-sub_pc_type", "shell", "-blasted_pc_type", "ilu0",
+                        "-blasted_async_sweeps", "3,3", "-blasted_async_fact_init_type", "init_original",
+                        "-blasted_async_apply_init_type", "init_zero", "-blasted_thread_chunk_size", "128",
+                        "-blasted_use_symmetric_scaling", "0"], capture_output=True, text=True)
+    assert "Found valid parent KSP for BLASTed" in r.stdout and "block_size = 4" in r.stdout
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
 def test_native_driver_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
@@ -170,3 +195,54 @@ def test_dense_matrix_market_reader(tmp_path):
     n = int(np.frombuffer(raw, np.int64, 1)[0])
     v = np.frombuffer(raw, np.float64, n, 8)
     np.testing.assert_array_equal(v, np.asarray(mtxio.read_mtx_dense(path)).ravel())
+
+
+# ---- PETSc-binary route of the host library (what the reference's PETSc drivers MatLoad / VecLoad) -----------
+
+@pytest.mark.parametrize("bs,order", [("info", "colmajor"), (4, "rowmajor"), (1, "colmajor")])
+def test_petsc_binary_matrix_equals_matrix_market(bs, order, tmp_path):
+    """COOMatrix::readPetscBinary on the reference's 2dcyl1.pmat (tests/input/fvens-2dcyl1; block size 4 from
+    2dcyl1.pmat.info's -matload_block_size, as MatLoad takes it) gives bit for bit the structure and values
+    of 2dcyl1.mtx read through the Matrix-Market route."""
+    import numpy as np
+    nbs = 4 if bs == "info" else bs
+    _, _, rp0, ci0, dg0, v0 = _coo_dump(os.path.join(GOLDEN, "2dcyl1.mtx"), nbs, order, tmp_path)
+    out = str(tmp_path / "p.bin")
+    subprocess.check_call([COO, os.path.join(GOLDEN, "2dcyl1.pmat"), str(bs), order, out])
+    raw = open(out, "rb").read()
+    nb, nnzb = np.frombuffer(raw, np.int32, 2)
+    assert nb == 1784 // nbs and nnzb == len(ci0)
+    o = 8
+    np.testing.assert_array_equal(np.frombuffer(raw, np.int32, nb + 1, o), rp0); o += 4 * (nb + 1)
+    np.testing.assert_array_equal(np.frombuffer(raw, np.int32, nnzb, o), ci0); o += 4 * nnzb
+    np.testing.assert_array_equal(np.frombuffer(raw, np.int32, nb, o), dg0); o += 4 * nb
+    np.testing.assert_array_equal(np.frombuffer(raw, np.float64, nnzb * nbs * nbs, o), v0)
+
+
+@pytest.mark.parametrize("name", ["2dcyl1_b", "2dcyl1_x"])
+def test_petsc_binary_vector_equals_matrix_market(name, tmp_path):
+    import numpy as np
+    from blasted_amd import mtxio
+    out = str(tmp_path / "v.bin")
+    subprocess.check_call([COO, os.path.join(GOLDEN, name + ".pmat"), "dense", out])
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw, np.int64, 1)[0])
+    v = np.frombuffer(raw, np.float64, n, 8)
+    np.testing.assert_array_equal(v, np.asarray(mtxio.read_mtx_dense(os.path.join(GOLDEN, name + ".mtx"))).ravel())
+    np.testing.assert_array_equal(v, mtxio.read_petsc_vec(os.path.join(GOLDEN, name + ".pmat")))
+
+
+def test_petsc_binary_reader_rejects_malformed_files(tmp_path):
+    import numpy as np
+    good = open(os.path.join(GOLDEN, "2dcyl1.pmat"), "rb").read()
+    cases = {"truncated.pmat": good[:-8], "notamatrix.pmat": open(os.path.join(GOLDEN, "2dcyl1_b.pmat"), "rb").read(),
+             "badlens.pmat": good[:16] + np.array([7], ">i4").tobytes() + good[20:], "empty.pmat": b""}
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        r = subprocess.run([COO, str(p), "4", "colmajor", str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 3 and "MatrixReadException" in r.stderr, (name, r.returncode, r.stderr)
+    # a matrix file is not a vector either
+    r = subprocess.run([COO, os.path.join(GOLDEN, "2dcyl1.pmat"), "dense", str(tmp_path / "o.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 3

@@ -18,6 +18,16 @@ def one(pattern):
     return f[0] if f else None
 
 
+# bench config number -> (key in profiles/traffic.json = the workload name, name fragments of its dominant kernel)
+CONFIG_KERNELS = {
+    "1": ("poisson3d_64_csr_async_ilu0_apply", ("sweep_kernel<1, false, 1,",)),
+    "2": ("ilu_apply", ("sweepw_kernel<4, 1,", "sweep_kernel<")),
+    "3": ("poisson3d_256_bs4_async_block_sgs_relaxation", ("sweepw_kernel<4, 2,",)),
+    "4": ("unstructured_126_bs5_async_block_ilu0_apply", ("sweepodd_kernel<5, 1,", "sweepx_kernel<5, 1,")),
+    "5": ("poisson3d_100_bs8_block_ilu0_apply", ("sweepw_kernel<8, 1,",)),
+}
+
+
 def main(tag, op="ilu_apply"):
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
@@ -42,6 +52,26 @@ def main(tag, op="ilu_apply"):
         for k, v in agg.items():
             pmc.setdefault(k, {})[name + "_KB_avg"] = sum(v) / len(v)
             pmc[k]["launches_" + name] = len(v)
+    # the other counter passes (SQ, L2): per-kernel averages, and the ratios they are read for
+    for pat in ("prof_%s_sq/*/*_counter_collection.csv", "prof_%s_tcc/*/*_counter_collection.csv"):
+        f = one(pat % tag)
+        if not f:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if "bhip::" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            for cn, v in cs.items():
+                pmc.setdefault(k, {})[cn + "_avg"] = sum(v) / len(v)
+    for k, d in pmc.items():
+        if d.get("SQ_WAVE_CYCLES_avg"):
+            for cn in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                if cn + "_avg" in d:
+                    d[cn + "_frac_of_wave_cycles"] = d[cn + "_avg"] / d["SQ_WAVE_CYCLES_avg"]
+        if d.get("TCC_HIT_sum_avg") is not None and d.get("TCC_MISS_sum_avg") is not None:
+            tot = d["TCC_HIT_sum_avg"] + d["TCC_MISS_sum_avg"]
+            d["L2_hit_rate"] = d["TCC_HIT_sum_avg"] / tot if tot else None
     for k, d in pmc.items():
         if "FETCH_SIZE_KB_avg" in d and "WRITE_SIZE_KB_avg" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_KB_avg"] + d["WRITE_SIZE_KB_avg"]) * 1024.0
@@ -52,6 +82,8 @@ def main(tag, op="ilu_apply"):
     want = {"ilu_apply": ("sweepw_kernel<4, 1,", "sweep_kernel<"), "sgs_apply": ("sweepw_kernel<4, 1,", "sweep_kernel<"),
             "sgs_relax": ("sweepw_kernel<4, 2,", "sweep_kernel<"), "spmv": ("sweepw_kernel<4, 3,", "sweep_kernel<"),
             "factor": ("factor4_kernel", "factor_sweep_kernel")}.get(op, ("sweepw_kernel",))
+    if op in CONFIG_KERNELS:  # "summarize_prof.py <tag> <config number>"
+        op, want = CONFIG_KERNELS[op]
     dom = []
     for w in want:
         dom = sorted([k for k in pmc if w in k and "hbm_bytes_per_launch" in pmc[k]],
@@ -63,7 +95,7 @@ def main(tag, op="ilu_apply"):
     if dom:
         cur[op] = {"kernel": dom[0], "hbm_bytes_per_launch": pmc[dom[0]]["hbm_bytes_per_launch"], "from": tag}
         json.dump(cur, open(tf, "w"), indent=1)
-    print(json.dumps(pmc, indent=1)[:3000])
+    print(json.dumps(pmc, indent=1)[:6000])
 
 
 if __name__ == "__main__":
