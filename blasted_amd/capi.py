@@ -29,7 +29,8 @@ SYMBOLS = [
     "blasted_hip_set_tuning",
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
     "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
-    "blasted_hip_device_synchronize", "blasted_hip_memory_stats",
+    "blasted_hip_device_synchronize", "blasted_hip_memory_stats", "blasted_hip_host_register",
+    "blasted_hip_host_unregister",
 ]
 
 _lib = None
@@ -78,6 +79,8 @@ def lib():
         _lib.blasted_hip_get_levels.argtypes = [vp, vp, vp, vp]
         _lib.blasted_hip_level_stats.argtypes = [vp, vp]
         _lib.blasted_hip_memory_stats.argtypes = [vp, vp]
+        _lib.blasted_hip_host_register.argtypes = [vp, C.c_ulong]
+        _lib.blasted_hip_host_unregister.argtypes = [vp]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
         _lib.blasted_hip_gemv3.argtypes = [vp, cd, vp, cd, vp, vp, ci]
         for nm in ("iluvals", "dblocks", "scale", "ytemp"):
@@ -128,6 +131,15 @@ def measure_read_stream(tensor, reps=10):
 def set_tuning(spec):
     """Process-wide kernel-variant selection (measurements only)."""
     _check(lib().blasted_hip_set_tuning(None if spec is None else spec.encode()))
+
+
+def host_register(a):
+    """Page-locks a numpy array in place (the caller keeps it alive until host_unregister)."""
+    _check(lib().blasted_hip_host_register(a.ctypes.data, a.nbytes))
+
+
+def host_unregister(a):
+    _check(lib().blasted_hip_host_unregister(a.ctypes.data))
 
 
 def device_count():

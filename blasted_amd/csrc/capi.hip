@@ -202,83 +202,24 @@ struct Phase {
 };
 
 // ---- pinned staging of caller-owned host arrays ----------------------------------------------
-// PETSc hands the PCSHELL callbacks plain pageable arrays (VecGetArray, the Mat's value array), and a Krylov
-// solver hands over the SAME few work vectors again and again.  A host range that is seen a second time is
-// page-locked in place (hipHostRegister), so that every later copy is a direct DMA instead of a staged
-// pageable copy; ranges seen once never pay for a registration.  A small process-wide LRU table; entries are
-// unregistered when they fall out or at process exit.  BLASTED_HIP_PIN=0 switches it off.  (A range the
-// caller frees while registered is harmless: ROCm tracks registered ranges through MMU notifiers, and the
-// stale entry is evicted like any other.)
+// PETSc hands the PCSHELL callbacks plain pageable arrays (VecGetArray, the Mat's value array).  A caller that
+// controls the lifetime of such an array can page-lock it in place (blasted_hip_host_register /
+// _unregister), so that copies from and to it are direct DMA instead of the runtime's staged pageable copy.
+// It is the CALLER's decision: a range that is freed while registered leaves a stale entry in the HIP
+// runtime's table, and a later copy that touches a new allocation overlapping it fails with "invalid
+// argument" -- which is what an automatic "register whatever is seen twice" table did to a numpy test that
+// frees and reallocates its arrays (round 2, tests/test_gpu_fuzz.py), so there is no such automatism.
 namespace {
 
 struct PinTable {
-	struct Ent {
-		uintptr_t lo, hi;
-		unsigned long stamp;
-		bool registered;
-	};
 	std::mutex mu;
-	std::vector<Ent> ents;
-	unsigned long clock = 0;
-	long registered_bytes = 0, registrations = 0;
-	bool enabled = [] {
-		const char *e = std::getenv("BLASTED_HIP_PIN");
-		return !(e && e[0] == '0');
-	}();
+	std::map<uintptr_t, size_t> ranges;
+	long registered_bytes = 0;
 
 	~PinTable()
 	{
-		for (auto &e : ents)
-			if (e.registered)
-				(void)hipHostUnregister(reinterpret_cast<void *>(e.lo));
-	}
-
-	void touch(const void *p, size_t nbytes)
-	{
-		constexpr size_t MIN_BYTES = 1u << 20;
-		constexpr size_t MAX_ENTS = 16;
-		if (!enabled || !p || nbytes < MIN_BYTES)
-			return;
-		const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + nbytes;
-		std::lock_guard<std::mutex> lk(mu);
-		clock++;
-		for (size_t i = 0; i < ents.size(); i++) {
-			Ent &e = ents[i];
-			if (lo >= e.lo && hi <= e.hi) {  // seen before
-				e.stamp = clock;
-				if (!e.registered) {
-					if (hipHostRegister(reinterpret_cast<void *>(e.lo), e.hi - e.lo, hipHostRegisterDefault) == hipSuccess) {
-						e.registered = true;
-						registered_bytes += (long)(e.hi - e.lo);
-						registrations++;
-					} else {
-						(void)hipGetLastError();  // not pinnable: stays pageable, never retried
-						e.lo = e.hi = 0;
-					}
-				}
-				return;
-			}
-			if (lo < e.hi && hi > e.lo) {  // overlaps an old entry without lying inside it: that entry is stale
-				if (e.registered) {
-					(void)hipHostUnregister(reinterpret_cast<void *>(e.lo));
-					registered_bytes -= (long)(e.hi - e.lo);
-				}
-				ents.erase(ents.begin() + (long)i);
-				i--;
-			}
-		}
-		if (ents.size() >= MAX_ENTS) {
-			size_t victim = 0;
-			for (size_t i = 1; i < ents.size(); i++)
-				if (ents[i].stamp < ents[victim].stamp)
-					victim = i;
-			if (ents[victim].registered) {
-				(void)hipHostUnregister(reinterpret_cast<void *>(ents[victim].lo));
-				registered_bytes -= (long)(ents[victim].hi - ents[victim].lo);
-			}
-			ents.erase(ents.begin() + (long)victim);
-		}
-		ents.push_back({lo, hi, clock, false});  // first sighting: remember, do not register yet
+		for (auto &kv : ranges)
+			(void)hipHostUnregister(reinterpret_cast<void *>(kv.first));
 	}
 };
 
@@ -294,7 +235,6 @@ static const double *in_vec(blasted_hip_prec p, const double *v, int loc, int sl
 	if (loc == BLASTED_HIP_DEVICE)
 		return v;
 	double *d = ensure(p->stage[slot], p->n());
-	g_pins.touch(v, sizeof(double) * (size_t)p->n());
 	BHIP_CHECK(hipMemcpyAsync(d, v, sizeof(double) * p->n(), hipMemcpyHostToDevice, p->stream));
 	return d;
 }
@@ -310,7 +250,6 @@ static void finish_out(blasted_hip_prec p, double *host, const double *dev, int 
 {
 	if (loc == BLASTED_HIP_DEVICE)
 		return;
-	g_pins.touch(host, sizeof(double) * (size_t)p->n());
 	BHIP_CHECK(hipMemcpyAsync(host, dev, sizeof(double) * p->n(), hipMemcpyDeviceToHost, p->stream));
 	BHIP_CHECK(hipStreamSynchronize(p->stream));
 }
@@ -556,6 +495,9 @@ static int g_interleave = [] {
 	return (e && e[0] == '1') ? 1 : 0;
 }();
 
+// tuning ("xcdsuper=N", N a power of two): the XCDs take turns on super-chunks of N consecutive chunks (lanes.hpp)
+static int g_xcd_shift = 4;
+
 // tuning ("relaxsplit=0|1"): exact relaxation passes as product + exact triangular solve (default) or as one
 // whole-row exact kernel
 static int g_relax_split = 1;
@@ -570,6 +512,7 @@ static SweepArgs base_args(blasted_hip_prec p)
 	std::memset(&a, 0, sizeof(a));
 	a.pat = p->pat;
 	a.interleave = g_interleave;
+	a.xcd_shift = g_xcd_shift;
 	a.a = 1.0;
 	a.b = 0.0;
 	return a;
@@ -806,7 +749,6 @@ int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
 		} else {
 			if (!p->vals_own)
 				p->vals_own = dev_alloc<double>((size_t)p->nvals());
-			g_pins.touch(vals, sizeof(double) * (size_t)p->nvals());
 			BHIP_CHECK(hipMemcpyAsync(p->vals_own, vals, sizeof(double) * (size_t)p->nvals(),
 			                          hipMemcpyHostToDevice, p->stream));
 			BHIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1675,6 +1617,37 @@ int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned lo
 	});
 }
 
+int blasted_hip_host_register(void *host_ptr, unsigned long nbytes)
+{
+	return guarded([&] {
+		if (!host_ptr || nbytes == 0)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "host_register: null pointer or empty range");
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+			BHIP_FAIL(BLASTED_HIP_ENODEV, "no HIP device available: the MI355X backend has no CPU fallback");
+		std::lock_guard<std::mutex> lk(g_pins.mu);
+		const uintptr_t key = reinterpret_cast<uintptr_t>(host_ptr);
+		if (g_pins.ranges.count(key))
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "host_register: this address is registered already");
+		BHIP_CHECK(hipHostRegister(host_ptr, nbytes, hipHostRegisterDefault));
+		g_pins.ranges[key] = nbytes;
+		g_pins.registered_bytes += (long)nbytes;
+	});
+}
+
+int blasted_hip_host_unregister(void *host_ptr)
+{
+	return guarded([&] {
+		std::lock_guard<std::mutex> lk(g_pins.mu);
+		auto it = g_pins.ranges.find(reinterpret_cast<uintptr_t>(host_ptr));
+		if (it == g_pins.ranges.end())
+			BHIP_FAIL(BLASTED_HIP_ESTATE, "host_unregister: this address is not registered");
+		g_pins.registered_bytes -= (long)it->second;
+		g_pins.ranges.erase(it);
+		BHIP_CHECK(hipHostUnregister(host_ptr));
+	});
+}
+
 int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, int reps, double *gbps)
 {
 	return guarded([&] {
@@ -1725,14 +1698,22 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "sweepwr=", 8) == 0)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
-			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : spec[9] != '0'));
+			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
 		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)
 			set_factorodd_enabled(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "relaxsplit=", 11) == 0)
 			g_relax_split = spec[11] != '0';
-		else if (spec && std::strncmp(spec, "copies=", 7) == 0)
+		else if (spec && std::strncmp(spec, "xcdsuper=", 9) == 0) {
+			const int n = std::atoi(spec + 9);
+			int sh = 0;
+			while ((1 << sh) < n && sh < 12)
+				sh++;
+			if (n < 1 || (1 << sh) != n)
+				BHIP_FAIL(BLASTED_HIP_EINVAL, "xcdsuper: a power of two between 1 and 4096");
+			g_xcd_shift = sh;
+		} else if (spec && std::strncmp(spec, "copies=", 7) == 0)
 			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
 			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;

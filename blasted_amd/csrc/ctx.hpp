@@ -68,6 +68,7 @@ struct SweepArgs {
 	double *xnat;           // level-ordered exact solves: optional second output in natural row order
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
+	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp), default 4
 	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
 };
 
@@ -119,7 +120,7 @@ struct FactorArgs {
 	const int *posptr, *lowerp, *upperp;
 	const double *in;       // factor values read
 	double *out;            // factor values written (== in for async)
-	double *dinv_scratch;   // optional nbrows*bs*bs scratch (bs=8 tuned path: inverted diagonal blocks)
+	double *dinv_scratch;   // optional nbrows*bs*bs array (bs >= 5): receives the inverted diagonal blocks of `in`
 	const int *rows;        // optional row list (level-scheduled exact factorisation), else all rows
 	int nrows;              // length of `rows`
 	int diag_inverted;      // exact factorisation, bs > 1: diagonal blocks are stored inverted as soon as they are
@@ -231,7 +232,7 @@ struct blasted_hip_prec_s {
 	long npairs = -1;
 
 	double *iluvals = nullptr, *iluvals2 = nullptr;
-	double *finv = nullptr;  // inverted diagonal blocks of the current iterate (bs=8 factorisation sweeps)
+	double *finv = nullptr;  // inverted diagonal blocks of the current iterate (bs >= 5 factorisation sweeps)
 	double *fdiag = nullptr;  // the factor's (inverted) diagonal blocks, contiguous: first synchronous upper sweep
 	bool fdiag_valid = false;
 	double *scale = nullptr;

@@ -241,6 +241,14 @@ __global__ __launch_bounds__(256) void invert_blocks_kernel(const Pattern pat, c
 // threads through an LDS transpose, so that global loads and stores stay coalesced (a wave instruction
 // moves one whole block).  All register-array indices are compile-time constants (row swaps and the
 // final column un-permutation are conditional moves).
+// (Round 2, bs = 8, where this pass is a quarter of a factorisation sweep -- 0.74 ms per 10^6 blocks, 1 GB at
+// 1.4 TB/s, four waves per CU because of its 215 VGPRs and 33 KB of LDS: two wave-cooperative replacements were
+// built, verified and removed.  A wave inverting one block with lane (r,c) = entry (r,c), Gauss-Jordan without
+// row moves, three ds_bpermute exchanges and a DPP pivot search per step, ~50 VGPRs, coalesced 512-byte loads,
+// as a pre-pass: 1.0 ms.  The same routine inside the factor kernel, run by the wave that has just finished a
+// row's diagonal block, so that no pre-pass is needed after the first sweep: the sweep kernel went from 2.07 to
+// 2.43 ms.  Eight dependent steps of cross-lane exchanges are a longer critical path than 64 independent
+// register-resident eliminations; the thread-per-block form stays.)
 template <int BS, bool RM>
 __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat, const double *src,
                                                                const int src_by_diag, double *dst,

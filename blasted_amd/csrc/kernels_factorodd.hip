@@ -23,7 +23,7 @@ typedef double fd2_t __attribute__((ext_vector_type(2)));
 typedef fd2_t fd2u_t __attribute__((aligned(8)));
 
 template <int BS>
-__global__ __launch_bounds__(256) void factorodd_kernel(const FactorArgs a, const double *__restrict__ dinv)
+__global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, const double *__restrict__ dinv)
 {
 	static_assert(BS == 5 || BS == 7, "odd block sizes 5, 7");
 	constexpr int BS2 = BS * BS, L = (BS2 + 1) / 2;

@@ -42,8 +42,11 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 }
 
 // NT: the block stream is read with non-temporal loads (tuning "sweepodd=nt0" / "sweepodd=nt1").
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true>
-__global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
+// OCC: waves per SIMD the register allocation must leave room for (second launch bound).  Left alone the
+// compiler spends 78-86 VGPRs on the triangular sweeps (5 waves per SIMD); asked for 6 it needs 62-70 without a
+// spill, i.e. 7-8 resident waves -- and resident waves are bytes in flight, which is what bounds this kernel.
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 {
 	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
 	constexpr int BS2 = BS * BS, L = (BS2 + 1) / 2;     // lanes that hold a block
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 	const bool hiA = cA != cx, hiB = cB != cx;
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)a.xcd_shift);
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;
@@ -89,78 +92,96 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 	double *const tile = &s_acc[wave][g][0];
 	double *const wvec = &s_w[wave][g][0];
 
-	for (int step = 0; step < RCHUNK / RSTEP; step++) {
+	// One row step = the loads of a step (index look-up, KFIX straight-line block passes with their x pairs,
+	// D block, right-hand side), the multiply-accumulate, and the reduction through the wave-private LDS tile.
+	// (Tried in round 2: software-pipelined steps -- the loads of step s+1 issued into the freed load registers
+	// before the LDS reduction and the store of step s.  Bit-identical for synchronous sweeps and no faster on
+	// any of bs 3 / 5 / 7 (+-0.3 %), while the state carried across iterations cost 14 VGPRs = one wave per
+	// SIMD and 7 % on the unstructured case: what bounds this kernel is bytes in flight per CU, i.e. resident
+	// waves, not the LDS round trips.)
+	struct Step {
+		d2_t bv[KFIX], xv[KFIX];
+		d2_t dv;
+		double rv;
+		int jbeg, jend, dg, lr;
+		bool ok;
+	};
+	auto issue = [&](const int step, Step &q) {
 		const int ls = step * RSTEP + wave * RPW + g;  // position in sweep order
-		const bool ok = ls < rc;
-		const int lr = ok ? (a.descending ? rc - 1 - ls : ls) : 0;
-		const int rp0 = s_rp[lr], rp1 = s_rp[lr + 1], dg = s_dg[lr];
-		int jbeg = 0, jend = 0;
-		if (ok) {
+		q.ok = ls < rc;
+		q.lr = q.ok ? (a.descending ? rc - 1 - ls : ls) : 0;
+		const int rp0 = s_rp[q.lr], rp1 = s_rp[q.lr + 1];
+		q.dg = s_dg[q.lr];
+		q.jbeg = q.jend = 0;
+		if (q.ok) {
 			if (PART == PART_LOWER) {
-				jbeg = rp0;
-				jend = dg;
+				q.jbeg = rp0;
+				q.jend = q.dg;
 			} else if (PART == PART_UPPER) {
-				jbeg = DIAG_RIDES ? dg : dg + 1;  // first item = the (inverted) diagonal block
-				jend = rp1;
+				q.jbeg = DIAG_RIDES ? q.dg : q.dg + 1;  // first item = the (inverted) diagonal block
+				q.jend = rp1;
 			} else if (PART == PART_OFFDIAG || PART == PART_ALL) {
-				jbeg = rp0;
-				jend = rp1;
+				q.jbeg = rp0;
+				q.jend = rp1;
 			}
 		}
-
-		d2_t bv[KFIX], xv[KFIX];
 #pragma unroll
 		for (int k = 0; k < KFIX; k++) {
-			const int jj = jbeg + k;
-			bv[k].x = bv[k].y = 0.0;
-			xv[k].x = xv[k].y = 0.0;
+			const int jj = q.jbeg + k;
+			q.bv[k].x = q.bv[k].y = 0.0;
+			q.xv[k].x = q.xv[k].y = 0.0;
 			// (relaxation: the diagonal block of A is not part of the sum -- do not fetch it)
-			if (PART != PART_NONE && jj < jend && actB && !(PART == PART_OFFDIAG && jj == dg)) {
-				bv[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
-				           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
-				const bool isdiag = (jj == dg);
+			if (PART != PART_NONE && jj < q.jend && actB && !(PART == PART_OFFDIAG && jj == q.dg)) {
+				q.bv[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
+				             : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
+				const bool isdiag = (jj == q.dg);
 				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {
 					const int cidx = jj - jlo;
 					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					xv[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
+					q.xv[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
 				}
 			}
 		}
-		d2_t dv;
-		dv.x = dv.y = 0.0;
-		if (DSRC == D_DBLOCKS && ok && actB)
-			dv = load16u(dbase + ((unsigned)lr * (unsigned)BLKBYTES + boff));
-		double rv = 0.0;
-		if (ok && t < BS && a.rhs) {
-			rv = *reinterpret_cast<const double *>(rbase + ((unsigned)lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
+		q.dv.x = q.dv.y = 0.0;
+		if (DSRC == D_DBLOCKS && q.ok && actB)
+			q.dv = load16u(dbase + ((unsigned)q.lr * (unsigned)BLKBYTES + boff));
+		q.rv = 0.0;
+		if (q.ok && t < BS && a.rhs) {
+			q.rv = *reinterpret_cast<const double *>(rbase + ((unsigned)q.lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
 			if (a.rscale)
-				rv *= *reinterpret_cast<const double *>(sbase + ((unsigned)lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
+				q.rv *= *reinterpret_cast<const double *>(sbase + ((unsigned)q.lr * (unsigned)ROWBYTES + 8u * (unsigned)t));
 		}
+	};
 
-		double sum = 0.0;  // component t of sum_j A_ij x_j, lanes t < 5
+	constexpr int NSTEPS = RCHUNK / RSTEP;
+	for (int step = 0; step < NSTEPS; step++) {
+		Step q;
+		issue(step, q);
+		// ---- products of this step (consumes the load registers)
+		double accA = 0.0, accB = 0.0;
+		d2_t dv = q.dv;
 		if (PART != PART_NONE) {
-			double accA = 0.0, accB = 0.0;
 #pragma unroll
 			for (int k = 0; k < KFIX; k++) {
 				if (DIAG_RIDES && k == 0) {
-					dv = bv[0];  // item 0 of the row is its diagonal block: xv[0] was not loaded (zero)
+					dv = q.bv[0];  // item 0 of the row is its diagonal block: xv[0] was not loaded (zero)
 				} else {
-					accA += bv[k].x * (hiA ? xv[k].y : xv[k].x);
-					accB += bv[k].y * (hiB ? xv[k].y : xv[k].x);
+					accA += q.bv[k].x * (hiA ? q.xv[k].y : q.xv[k].x);
+					accB += q.bv[k].y * (hiB ? q.xv[k].y : q.xv[k].x);
 				}
 			}
 			// rows longer than KFIX blocks (unstructured meshes: ~7 lower and ~8 diagonal+upper blocks at 14
 			// neighbours): the rest goes in groups of KGRP predicated straight-line passes, one memory round
 			// trip per group -- one block per iteration made every extra block a dependent round trip
 			constexpr int KGRP = 4;
-			for (int jb = jbeg + KFIX; jb < jend; jb += KGRP) {
+			for (int jb = q.jbeg + KFIX; jb < q.jend; jb += KGRP) {
 				d2_t v4[KGRP], x4[KGRP];
 #pragma unroll
 				for (int k = 0; k < KGRP; k++) {
 					const int jj = jb + k;
 					v4[k].x = v4[k].y = 0.0;
 					x4[k].x = x4[k].y = 0.0;
-					if (jj < jend && actB && !(PART == PART_OFFDIAG && jj == dg)) {
+					if (jj < q.jend && actB && !(PART == PART_OFFDIAG && jj == q.dg)) {
 						v4[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
 						           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
 						const int cidx = jj - jlo;
@@ -174,7 +195,14 @@ __global__ __launch_bounds__(256) void sweepodd_kernel(const SweepArgs a)
 					accB += v4[k].y * (hiB ? x4[k].y : x4[k].x);
 				}
 			}
-			// 25 partial products -> 5 components through the wave-private tile
+		}
+		const double rv = q.rv;
+		const bool ok = q.ok;
+		const int lr = q.lr;
+
+		// ---- 25 partial products -> 5 components through the wave-private tile
+		double sum = 0.0;  // component t of sum_j A_ij x_j, lanes t < BS
+		if (PART != PART_NONE) {
 			if (actA)
 				tile[eA] = accA;
 			if (actB)
@@ -226,23 +254,32 @@ int g_sweepodd_enabled = [] {
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 }();
 
-int g_sweepodd_nt = 1;  // tuning "sweepodd=nt0" / "sweepodd=nt1": bs=5 block stream with plain / non-temporal loads
+// tuning "sweepodd=nt0" (default) / "sweepodd=nt1": block stream with plain / non-temporal loads.  A block of
+// 72 / 200 / 392 bytes shares its first and last 128-byte line with its neighbours, which the next load
+// instruction of the same wave wants from the caches: same-process A/B, lower + upper sweep in ms, nt1 -> nt0:
+// unstructured bs=5 1.627 -> 1.557, Poisson 128^3 bs=3 0.416 -> 0.319, bs=5 0.848 -> 0.784, bs=7 1.438 -> 1.436.
+int g_sweepodd_nt = 0;
+int g_sweepodd_occ = 1;  // tuning "sweepodd=occ1" (default) / "sweepodd=occ0": occupancy-bounded register allocation
 
 template <int PART, int POST, int DSRC>
 void launch5(const SweepArgs &a, hipStream_t s)
 {
 	constexpr int RCHUNK = 128;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
+	constexpr int OCCT = (PART == PART_LOWER || PART == PART_UPPER) ? 6 : 1;
+#define BHIP_ODD(B)                                                                                                    \
+	if (g_sweepodd_nt)                                                                                                 \
+		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, true, 1>), dim3(grid), dim3(256), 0, s, a);    \
+	else if (g_sweepodd_occ)                                                                                           \
+		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, OCCT>), dim3(grid), dim3(256), 0, s, a); \
+	else                                                                                                               \
+		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, 1>), dim3(grid), dim3(256), 0, s, a);
 	switch (a.pat.bs) {
-	case 3: hipLaunchKernelGGL((sweepodd_kernel<3, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
-	case 5:
-		if (g_sweepodd_nt)
-			hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK, true>), dim3(grid), dim3(256), 0, s, a);
-		else
-			hipLaunchKernelGGL((sweepodd_kernel<5, PART, POST, DSRC, RCHUNK, false>), dim3(grid), dim3(256), 0, s, a);
-		break;
-	default: hipLaunchKernelGGL((sweepodd_kernel<7, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a); break;
+	case 3: BHIP_ODD(3) break;
+	case 5: BHIP_ODD(5) break;
+	default: BHIP_ODD(7) break;
 	}
+#undef BHIP_ODD
 }
 
 }  // namespace
@@ -251,6 +288,8 @@ void set_sweepodd_enabled(int on)
 {
 	if (on == 2 || on == 3)  // "sweepodd=nt1" / "sweepodd=nt0"
 		g_sweepodd_nt = on == 2 ? 1 : 0;
+	else if (on == 4 || on == 5)  // "sweepodd=occ1" / "sweepodd=occ0"
+		g_sweepodd_occ = on == 4 ? 1 : 0;
 	else
 		g_sweepodd_enabled = on;
 }

@@ -83,7 +83,13 @@ __device__ __forceinline__ void sc_store(char *p, const double v)
 	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false>
+// LR ("long rows"): what happens to the blocks of a row part beyond the KFIX straight-line passes.  false:
+// one block per loop iteration -- costs no registers, and never runs on stencil matrices whose parts fit the
+// straight-line passes (the headline case: 48-54 VGPRs, 8 waves per SIMD).  true: groups of four predicated
+// straight-line passes, one memory round trip per group instead of one per block, for patterns with longer
+// rows (unstructured meshes); the group's registers take the kernel to 74-78 VGPRs, 6 waves per SIMD, which
+// is why it is a separate instantiation chosen by the pattern's longest row.
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false, bool LR = false>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
 	using Ge = WGeo<BS, NBV>;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	const int c = q / HB, h = q % HB;  // column of this lane's two entries, row pair (2h, 2h+1)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)a.xcd_shift);
 	// rows of this chunk in index order: [r0, r0 + rc)
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
@@ -282,30 +288,43 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 						acc1 += bv[u][k].y * xv[u][k];
 					}
 				}
-				// longer rows: the rest in groups of KGRP predicated straight-line passes -- one memory round
-				// trip per group instead of one per block
-				constexpr int KGRP = 4;
-				for (int jb = jbeg[u] + slot + KFIX * NB; jb < jend[u]; jb += KGRP * NB) {
-					double2_t v4[KGRP];
-					double x4[KGRP];
-#pragma unroll
-					for (int k = 0; k < KGRP; k++) {
-						const int jj = jb + k * NB;
-						v4[k].x = v4[k].y = 0.0;
-						x4[k] = 0.0;
-						if (jj < jend[u] && !(PART == PART_OFFDIAG && jj == dgp[u])) {
-							v4[k] = load_block16<NT>(reinterpret_cast<const double *>(
-							    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
-							const int cidx = jj - jlo;
-							const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-							const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
-							x4[k] = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
-						}
+				if (!LR) {
+					for (int jj = jbeg[u] + slot + KFIX * NB; jj < jend[u]; jj += NB) {
+						if (PART == PART_OFFDIAG && jj == dgp[u])
+							continue;
+						const double2_t v2 = load_block16<NT>(reinterpret_cast<const double *>(
+						    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+						const int cidx = jj - jlo;
+						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
+						const double xc = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
+						acc0 += v2.x * xc;
+						acc1 += v2.y * xc;
 					}
+				} else {
+					constexpr int KGRP = 4;
+					for (int jb = jbeg[u] + slot + KFIX * NB; jb < jend[u]; jb += KGRP * NB) {
+						double2_t v4[KGRP];
+						double x4[KGRP];
 #pragma unroll
-					for (int k = 0; k < KGRP; k++) {
-						acc0 += v4[k].x * x4[k];
-						acc1 += v4[k].y * x4[k];
+						for (int k = 0; k < KGRP; k++) {
+							const int jj = jb + k * NB;
+							v4[k].x = v4[k].y = 0.0;
+							x4[k] = 0.0;
+							if (jj < jend[u] && !(PART == PART_OFFDIAG && jj == dgp[u])) {
+								v4[k] = load_block16<NT>(reinterpret_cast<const double *>(
+								    vbase + ((unsigned)(jj - jlo) * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
+								const int cidx = jj - jlo;
+								const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+								const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 8u * (unsigned)c);
+								x4[k] = SC ? sc_load(xp) : *reinterpret_cast<const double *>(xp);
+							}
+						}
+#pragma unroll
+						for (int k = 0; k < KGRP; k++) {
+							acc0 += v4[k].x * x4[k];
+							acc1 += v4[k].y * x4[k];
+						}
 					}
 				}
 				// over the column bits and the block-slot bit; the row-pair bits h stay
@@ -434,9 +453,18 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 		if (v.sc && SCOK)                                                                              \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, true, 1, 1, SCOK>), dim3(grid),  \
 			                   dim3(256), 0, s, a);                                                    \
-		else if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1))                    \
-			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \
-			                   dim3(256), 0, s, a);                                                    \
+		else if (v.nb1 && (PART == PART_LOWER || PART == PART_UPPER || v.nb1 == 1)) {                  \
+			/* rows whose part can exceed the straight-line passes: the grouped remainder (LR) */          \
+			constexpr int KSTRAIGHT = (4 / 1) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);      \
+			const bool whole = PART == PART_ALL || PART == PART_OFFDIAG;                                   \
+			const int longest_part = whole ? a.pat.max_row_len : (a.pat.max_row_len + 1) / 2 + 1;          \
+			if (longest_part > KSTRAIGHT + 1 && UN1 == 1)                                                  \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, true>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else                                                                                           \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \
+				                   dim3(256), 0, s, a);                                                    \
+		}                                                                                              \
 		else                                                                                           \
 			hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UEFF, 2>), dim3(grid), \
 			                   dim3(256), 0, s, a);                                                    \

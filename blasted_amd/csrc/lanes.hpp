@@ -26,6 +26,17 @@ __device__ __forceinline__ unsigned xcd_chunk(unsigned bid, unsigned nwg)
 	return (local / S) * (8u * S) + xcd * S + local % S;
 }
 
+// the same mapping with a run-time super-chunk size 2^shift (tuning "xcdsuper=N"; shift 4 = the default above)
+__device__ __forceinline__ unsigned xcd_chunk(unsigned bid, unsigned nwg, unsigned shift)
+{
+	const unsigned S = 1u << shift;
+	const unsigned full = nwg - nwg % (8u * S);
+	if (bid >= full)
+		return bid;
+	const unsigned xcd = bid & 7u, local = bid >> 3;
+	return ((local >> shift) << (shift + 3)) + (xcd << shift) + (local & (S - 1u));
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(const double v)
 {

@@ -65,6 +65,9 @@ void device_buffer_download(void *host, const void *dev, std::size_t nbytes);
 /// waits for everything enqueued on the operators' device, on any stream (callers that mix the operators'
 /// private streams with another library's, e.g. the PCSHELL glue on PETSc's HIP vectors)
 void device_synchronize();
+/// page-lock / release a host range the caller owns (blasted_hip_host_register): false when it cannot be pinned
+bool host_register(const void *host, std::size_t nbytes);
+void host_unregister(const void *host);
 }  // namespace detail
 
 /// Aligned host array with an explicit mirror in HBM.  T must be plain old data.

@@ -40,6 +40,25 @@ struct LocalMatrix {
 	std::vector<PetscInt> ia, ja, diag;
 	Mat A = NULL;
 	const PetscScalar *vals = NULL;
+	// -blasted_pin_host_arrays: host ranges this operator page-locked (the value array, the vectors it was
+	// applied to), released with the operator
+	bool pin = false;
+	std::vector<const void *> pinned;
+	void pin_range(const void *p, const size_t nbytes)
+	{
+		if (!pin || !p || nbytes < (1u << 20) || pinned.size() >= 8)
+			return;
+		for (const void *q : pinned)
+			if (q == p)
+				return;
+		if (blasted::detail::host_register(p, nbytes))
+			pinned.push_back(p);
+	}
+	~LocalMatrix()
+	{
+		for (const void *q : pinned)
+			blasted::detail::host_unregister(q);
+	}
 };
 
 // side table: operator -> arrays this glue allocated for it (they must outlive the operator)
@@ -348,6 +367,15 @@ PetscErrorCode create_operator(PC pc)
 	}
 	ctx->bprec = reinterpret_cast<void *>(precop);
 	register_local_matrix(ctx->bprec, lm);  // released in cleanup_blasted together with the operator
+	// Not a reference option: page-lock the Mat's value array and the vectors the operator is applied to, so
+	// that the host-vector path copies by direct DMA.  Only for applications that keep these arrays alive
+	// until the PC is destroyed (PETSc's Mat and KSP work vectors are); off by default.
+	{
+		PetscBool set = PETSC_FALSE, val = PETSC_FALSE;
+		PetscOptionsGetBool(NULL, NULL, "-blasted_pin_host_arrays", &val, &set);
+		lm->pin = set && val;
+		lm->pin_range(lm->vals, sizeof(PetscScalar) * (size_t)lm->ia[nbr] * ctx->bs * ctx->bs);
+	}
 
 	ctx->infolist = NULL;
 	if (ctx->compute_precinfo) {
@@ -481,6 +509,11 @@ PetscErrorCode apply_local_blasted(PC pc, Vec r, Vec z)
 	PetscReal *za;
 	ierr = VecGetArray(z, &za); CHKERRQ(ierr);
 	ierr = VecGetArrayRead(r, &ra); CHKERRQ(ierr);
+	if (LocalMatrix *lm = local_matrix_of(ctx->bprec)) {
+		const size_t nbytes = sizeof(PetscReal) * (size_t)prec->dim();
+		lm->pin_range(ra, nbytes);
+		lm->pin_range(za, nbytes);
+	}
 	{
 		const StopWatch sw;
 		prec->apply(ra, za);  // host vectors: r H2D, sweeps, z D2H

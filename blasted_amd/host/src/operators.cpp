@@ -118,6 +118,14 @@ void device_synchronize()
 {
 	HipOperator::check(blasted_hip_device_synchronize(HipOperator::default_device()));
 }
+bool host_register(const void *host, const std::size_t nbytes)
+{
+	return blasted_hip_host_register(const_cast<void *>(host), nbytes) == BLASTED_HIP_OK;
+}
+void host_unregister(const void *host)
+{
+	(void)blasted_hip_host_unregister(const_cast<void *>(host));
+}
 
 }  // namespace detail
 

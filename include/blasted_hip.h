@@ -153,8 +153,8 @@ int blasted_hip_level_stats(blasted_hip_prec p, long *out4);
 /* HBM footprint: out4 = { bytes of device memory this operator holds now (pattern / value mirrors, factor,
  * derived copies, vectors, schedules), the peak of that figure, how many derived two-triangle copies of the
  * factor / matrix are resident (natural-order for the asynchronous sweeps, level-ordered for the exact
- * solves; at most one per array unless tuning "copies=both"), bytes of caller-owned host memory this
- * process has page-locked for staging (all operators) }.  Borrowed device arrays are not counted. */
+ * solves; at most one per array unless tuning "copies=both"), bytes of caller-owned host memory page-locked
+ * through blasted_hip_host_register (process-wide) }.  Borrowed device arrays are not counted. */
 int blasted_hip_memory_stats(blasted_hip_prec p, long *out4);
 /* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
  * inside a level), level_ptr[nlevels+1] */
@@ -183,6 +183,12 @@ int blasted_hip_buffer_alloc(void **dev_ptr, unsigned long nbytes, int device);
 int blasted_hip_buffer_free(void *dev_ptr);
 int blasted_hip_buffer_upload(void *dev_ptr, const void *host_ptr, unsigned long nbytes);
 int blasted_hip_buffer_download(void *host_ptr, const void *dev_ptr, unsigned long nbytes);
+/* Page-locks a caller-owned host range in place (hipHostRegister), so that the HOST-vector entry points and
+ * set_values copy from / to it by direct DMA instead of through the runtime's staged pageable copy.  For
+ * arrays whose lifetime the caller controls (the PCSHELL glue: the Mat's value array, the KSP's work vectors):
+ * unregister BEFORE the memory is freed.  Process-wide; the address is the key. */
+int blasted_hip_host_register(void *host_ptr, unsigned long nbytes);
+int blasted_hip_host_unregister(void *host_ptr);
 /* Measurement aid (bench.py's roofline object): the rate in GB/s at which this device streams nbytes of an
  * existing device buffer through a read-only kernel shaped like the sweeps' value stream (64 KiB per
  * workgroup, 16-byte non-temporal loads) -- the practical ceiling a sweep's algorithmic rate is read
