@@ -11,7 +11,7 @@ LIBPATH = os.path.join(HERE, "lib", "libblasted_hip.so")
 OK, EINVAL, ENODEV, ERUNTIME, ESTATE, ENOTIMPL = 0, 1, 2, 3, 4, 5
 COLMAJOR, ROWMAJOR = 0, 1
 HOST, DEVICE = 0, 1
-ASYNC, JACOBI_SYNC, LEVEL = 0, 1, 2
+ASYNC, JACOBI_SYNC, LEVEL, DETERMINISTIC = 0, 1, 2, 3
 INIT_F_ZERO, INIT_F_ORIGINAL, INIT_F_SGS, INIT_F_NONE = 0, 1, 2, 3
 INIT_A_ZERO, INIT_A_JACOBI, INIT_A_NONE = 0, 1, 2
 

@@ -262,8 +262,10 @@ static void check_loc(int loc)
 
 static void check_mode(int mode)
 {
-	if (mode != BLASTED_HIP_ASYNC && mode != BLASTED_HIP_JACOBI_SYNC && mode != BLASTED_HIP_LEVEL)
-		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC, BLASTED_HIP_JACOBI_SYNC or BLASTED_HIP_LEVEL");
+	if (mode != BLASTED_HIP_ASYNC && mode != BLASTED_HIP_JACOBI_SYNC && mode != BLASTED_HIP_LEVEL &&
+	    mode != BLASTED_HIP_DETERMINISTIC)
+		BHIP_FAIL(BLASTED_HIP_EINVAL, "mode must be BLASTED_HIP_ASYNC, BLASTED_HIP_JACOBI_SYNC, BLASTED_HIP_LEVEL or "
+		                              "BLASTED_HIP_DETERMINISTIC");
 }
 
 static LevelSchedule &need_levels(blasted_hip_prec p)
@@ -810,6 +812,10 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		use_device(p);
 		need_values(p);
 		check_mode(mode);
+		const bool deterministic = mode == BLASTED_HIP_DETERMINISTIC;
+		if (deterministic)
+			mode = BLASTED_HIP_JACOBI_SYNC;  // a fixed operator: synchronous sweeps (SGS apply: after an exact forward half)
+		(void)deterministic;
 		p->fac_lvl.invalidate();
 		p->fac_nat.invalidate();
 		p->fdiag_valid = false;
@@ -943,6 +949,10 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		use_device(p);
 		check_loc(loc);
 		check_mode(mode);
+		const bool deterministic = mode == BLASTED_HIP_DETERMINISTIC;
+		if (deterministic)
+			mode = BLASTED_HIP_JACOBI_SYNC;  // a fixed operator: synchronous sweeps (SGS apply: after an exact forward half)
+		(void)deterministic;
 		need_pattern(p);
 		if (!p->factored)
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_apply before ilu0_factorize");
@@ -1133,6 +1143,10 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		use_device(p);
 		check_loc(loc);
 		check_mode(mode);
+		const bool deterministic = mode == BLASTED_HIP_DETERMINISTIC;
+		if (deterministic)
+			mode = BLASTED_HIP_JACOBI_SYNC;  // a fixed operator: synchronous sweeps (SGS apply: after an exact forward half)
+		(void)deterministic;
 		need_jacobi(p);
 		if (!r || !z)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "sgs_apply: null vector");
@@ -1160,7 +1174,7 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		// asynchronous.  The product mode does the same: ONE exact in-order forward pass (repeating it changes
 		// nothing, and it does not read the initial ytemp), then napplysweeps asynchronous backward sweeps.
 		// "sgsfwd=async" restores napplysweeps asynchronous forward sweeps (round 1's form, a tuning variant).
-		if (mode == BLASTED_HIP_ASYNC && g_sgs_exact_fwd && napplysweeps >= 1 && p->pat.nbrows > 0) {
+		if (((mode == BLASTED_HIP_ASYNC && g_sgs_exact_fwd) || deterministic) && napplysweeps >= 1 && p->pat.nbrows > 0) {
 			SweepArgs f = base_args(p);
 			f.vals = p->vals;
 			f.dvals = p->dblocks;
@@ -1182,15 +1196,35 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 			if (g_compact)
 				compact_args(p, true, a, p->vals, p->mat_nat);
 			const double *first_in = nullptr;
+			int nbwd = napplysweeps;
 			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
 				first_in = p->ytemp;  // z0 = y: the first sweep gathers from y
 			else if (apply_init == BLASTED_HIP_INIT_A_ZERO) {
-				Phase ph(p, 2);
-				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
-				ph.launches = 1;
-				ph.done();
+				if (jac) {
+					// a synchronous backward sweep from z0 = 0 is z1 = y (the skipped products are with zeros):
+					// continue as from z0 = y with one sweep less
+					first_in = p->ytemp;
+					nbwd = napplysweeps - 1;
+				} else {
+					Phase ph(p, 2);
+					BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
+					ph.launches = 1;
+					ph.done();
+				}
+			} else if (jac) {
+				// INIT_A_NONE: synchronous sweeps need the initial z in a buffer sweep 1 does not write
+				double *z0 = ensure(p->tmp[0], n);
+				BHIP_CHECK(hipMemcpyAsync(z0, dz, nbytes, hipMemcpyDeviceToDevice, p->stream));
+				first_in = z0;
 			}
-			run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, nullptr, first_in, napplysweeps, mode, 1);
+			if (nbwd == 0)
+				BHIP_CHECK(hipMemcpyAsync(dz, p->ytemp, nbytes, hipMemcpyDeviceToDevice, p->stream));
+			else {
+				double *zo = jac ? ensure(p->tmp[1], n) : nullptr;
+				double *zfinal = run_sweeps(p, a, PART_UPPER, POST_SUB_D, D_DBLOCKS, dz, zo, first_in, nbwd, mode, 1);
+				if (zfinal != dz)
+					BHIP_CHECK(hipMemcpyAsync(dz, zfinal, nbytes, hipMemcpyDeviceToDevice, p->stream));
+			}
 			finish_out(p, z, dz, loc);
 			return;
 		}
@@ -1266,6 +1300,10 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 		use_device(p);
 		check_loc(loc);
 		check_mode(mode);
+		const bool deterministic = mode == BLASTED_HIP_DETERMINISTIC;
+		if (deterministic)
+			mode = BLASTED_HIP_JACOBI_SYNC;  // a fixed operator: synchronous sweeps (SGS apply: after an exact forward half)
+		(void)deterministic;
 		need_jacobi(p);
 		if (!b || !x || maxits < 0)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "relaxation: null vector or negative iteration count");

@@ -44,7 +44,7 @@ public:
 	void bind(const CRawBSRMatrix<double, int> &mat, int bs, StorageOptions stor);
 	blasted_hip_prec_s *get() const { return h; }
 	static void check(int rc);
-	/// BLASTED_HIP_ASYNC unless the environment asks for deterministic synchronous sweeps
+	/// how ilu0 / sgs apply their sweeps: BLASTED_HIP_DETERMINISTIC unless BLASTED_HIP_SWEEP_MODE says otherwise
 	static int sweep_mode();
 	static int default_device();
 

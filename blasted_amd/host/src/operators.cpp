@@ -46,19 +46,38 @@ int HipOperator::default_device()
 
 int HipOperator::sweep_mode()
 {
-	// BLASTED_HIP_EXACT_APPLY=1: the application of every asynchronous type (ilu0, sgs) runs as exact
-	// level-scheduled passes -- the limit the sweeps converge to, cheaper than three of them on this GPU
-	// and, unlike a few Jacobi-like sweeps of thousands of concurrent waves, as accurate as the
-	// reference's nearly sequential threaded sweeps ("End to end").  Factorisation and the
-	// relaxations keep their asynchronous form.
+	// How the asynchronous types (ilu0, sgs) APPLY their sweeps -- BLASTED_HIP_SWEEP_MODE:
+	//  * "deterministic" (default): synchronous Jacobi sweeps at the configured counts (SGS: after the exact
+	//    forward half the reference has too).  A fixed linear operator, bit-identical from call to call.  Inside
+	//    BiCGStab / CG / plain GMRES the in-place asynchronous sweeps of thousands of concurrent waves differ
+	//    enough between two applications to make the iteration diverge (256^3 Poisson, bs = 4, 3 and 5 sweeps:
+	//    profiles/r02_scope_ab.txt), where the reference's nearly sequential threaded sweeps do not; the same
+	//    number of synchronous sweeps converges, and costs less (their first sweep from zero needs no matrix).
+	//  * "async": the reference's chaotic in-place sweeps -- what bench.py measures; for flexible outer
+	//    iterations (FGMRES, pseudo-time stepping with nonlinear updates).
+	//  * "exact": every application as exact level-scheduled passes, whatever the sweep count -- the limit the
+	//    sweeps converge to, and on this GPU cheaper than three of them.
+	// Legacy switches: BLASTED_HIP_EXACT_APPLY=1 = "exact", BLASTED_HIP_SYNC_SWEEPS=1 = synchronous sweeps in
+	// every entry point (factorisation and relaxations too: the parity tests' mode).
 	const char *x = std::getenv("BLASTED_HIP_EXACT_APPLY");
 	if (x && std::atoi(x) != 0)
 		return BLASTED_HIP_LEVEL;
 	const char *e = std::getenv("BLASTED_HIP_SYNC_SWEEPS");
-	return (e && std::atoi(e) != 0) ? BLASTED_HIP_JACOBI_SYNC : BLASTED_HIP_ASYNC;
+	if (e && std::atoi(e) != 0)
+		return BLASTED_HIP_JACOBI_SYNC;
+	const char *m = std::getenv("BLASTED_HIP_SWEEP_MODE");
+	if (m && std::strcmp(m, "async") == 0)
+		return BLASTED_HIP_ASYNC;
+	if (m && std::strcmp(m, "exact") == 0)
+		return BLASTED_HIP_LEVEL;
+	if (m && std::strcmp(m, "deterministic") != 0 && std::strcmp(m, "sync") != 0)
+		throw std::invalid_argument("BLASTED_HIP_SWEEP_MODE must be deterministic, async or exact");
+	return BLASTED_HIP_DETERMINISTIC;
 }
 
-// the mode for entry points that do not take LEVEL (factorisation) or must stay asynchronous
+// the mode for entry points that keep the reference's chaotic form by default: the factorisation sweeps (their
+// result is fixed once compute() returns; synchronous sweeps would need a second copy of the factor) and the
+// relaxations (smoothers; a synchronous "Gauss-Seidel" step is a Jacobi step)
 static int async_or_sync_mode()
 {
 	const char *e = std::getenv("BLASTED_HIP_SYNC_SWEEPS");

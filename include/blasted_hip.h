@@ -50,8 +50,12 @@ enum { BLASTED_HIP_HOST = 0, BLASTED_HIP_DEVICE = 1 };
  * double-buffered synchronous Jacobi sweeps, deterministic; used by the parity tests.  LEVEL: every
  * sweep is one exact in-order pass, run as one launch per dependency level (the reference's
  * level-scheduled operators, src/solverops_levels_ilu0.cpp:58-105, src/solverops_levels_sgs.cpp:52-123);
- * accepted by the apply / relaxation entry points, not by ilu0_factorize. */
-enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1, BLASTED_HIP_LEVEL = 2 };
+ * accepted by the apply / relaxation entry points, not by ilu0_factorize.  DETERMINISTIC: the product mode for
+ * callers that need a FIXED linear operator (any non-flexible Krylov method): synchronous sweeps like
+ * JACOBI_SYNC -- the same sweep counts, run-to-run identical results -- except that the forward half of
+ * sgs_apply is the exact in-order solve, as it is in the reference at every thread count
+ * (src/solverops_sgs.cpp:62-66).  What the host C++ layer passes by default. */
+enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1, BLASTED_HIP_LEVEL = 2, BLASTED_HIP_DETERMINISTIC = 3 };
 
 /* include/async_initialization_decl.hpp:15-34, same numeric values as FactInit / ApplyInit */
 enum { BLASTED_HIP_INIT_F_ZERO = 0, BLASTED_HIP_INIT_F_ORIGINAL = 1, BLASTED_HIP_INIT_F_SGS = 2,

@@ -412,6 +412,40 @@ def test_sgs_apply_forward_half_is_exact_at_low_sweep_counts(golden, case):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_csr", "poisson12_bs5", "poisson9_bs8", "random_bs4", "random_csr"])
+def test_deterministic_mode(golden, case):
+    """BLASTED_HIP_DETERMINISTIC, the host layer's default: a fixed operator.  ILU apply = the synchronous
+    sweeps of JACOBI_SYNC; SGS apply = exact forward half + synchronous backward sweeps; bit-identical from
+    call to call."""
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)
+    f = p.get_iluvals()
+    for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+        for nsw in (1, 3):
+            z = p.ilu0_apply(r, nsw, init=init, mode=capi.DETERMINISTIC)
+            assert np.array_equal(z, p.ilu0_apply(r, nsw, init=init, mode=capi.JACOBI_SYNC))
+            assert rel(z, O.ilu0_apply(m, f, r, nsw, mode=O.JACOBI_SYNC, init=init)) < TOL_SYNC
+    p.jacobi_compute()
+    gd = p.get_dblocks()
+    ze, ye = O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL, return_y=True)
+    for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+        for nsw in (1, 2, 3):
+            z = p.sgs_apply(r, nsw, init=init, mode=capi.DETERMINISTIC)
+            assert rel(p.get_ytemp(), ye) < 1e-12
+            z0 = np.zeros(n) if init == capi.INIT_A_ZERO else ye
+            want = O.sgs_apply(m, gd, r, nsw, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=z0)
+            assert rel(z, want) < 1e-12
+            assert np.array_equal(z, p.sgs_apply(r, nsw, init=init, mode=capi.DETERMINISTIC))
+    # INIT_A_NONE: z is the initial guess of the backward sweeps
+    z0 = 0.5 * np.cos(np.arange(n))
+    z = p.sgs_apply(r, 2, init=capi.INIT_A_NONE, mode=capi.DETERMINISTIC, out=z0.copy())
+    assert rel(z, O.sgs_apply(m, gd, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=z0)) < 1e-12
+    p.close()
+
+
 def test_sgs_relax_async_reduces_residual(golden):
     """config 3: async block-SGS relaxation, 5 sweeps; asynchronous result lies between the
     synchronous-Jacobi and the serial Gauss-Seidel iterates in residual."""

@@ -37,7 +37,7 @@ def run(tmp_path, petsc_opts, mat_type="baij", vec_type="seq", pc=("bjacobi", "s
     cmd = [DRIVER, "--mat_file", PMAT, "--mat_type", mat_type, "--vec_type", vec_type, "--out", out] + list(extra) + \
           ["--"] + tree + list(petsc_opts)
     e = dict(os.environ)
-    for k in ("BLASTED_HIP_SYNC_SWEEPS", "BLASTED_HIP_EXACT_APPLY"):
+    for k in ("BLASTED_HIP_SYNC_SWEEPS", "BLASTED_HIP_EXACT_APPLY", "BLASTED_HIP_SWEEP_MODE"):
         e.pop(k, None)
     e.update(env or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e)
@@ -137,17 +137,34 @@ def test_pcshell_sgs_apply_and_richardson(tmp_path, mat_type, vec_type):
     assert rel(vecs["x"], O.sgs_relax(m, d, r, maxits=4, mode=O.JACOBI_SYNC)) < 1e-11
 
 
-def test_pcshell_sgs_product_mode_forward_half_exact(tmp_path):
-    """default (asynchronous) mode at the reference's low sweep count: z is no farther from the exact SGS
-    application than synchronous Jacobi backward sweeps from the exact forward solve (Q3)."""
+@pytest.mark.parametrize("sweep_mode", [None, "async"])
+def test_pcshell_sgs_product_modes_forward_half_exact(tmp_path, sweep_mode):
+    """the reference's low sweep count in the two product modes.  Default (deterministic): exact forward half,
+    then synchronous backward sweeps -- equal to the oracle's composition of the two.  BLASTED_HIP_SWEEP_MODE=
+    async (the reference's chaotic sweeps): z is no farther from the exact SGS application than that (Q3)."""
     m = matrix("baij")
-    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,2"] + ASYNC_OPTS)
-    check_common(rep, vecs, 4)
+    env = {"BLASTED_HIP_SWEEP_MODE": sweep_mode} if sweep_mode else None
+    rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,2"] + ASYNC_OPTS, env=env)
+    check_common(rep, vecs, 4, homogeneous=sweep_mode is None)  # (chaotic sweeps are not reproducible to the last bit)
     r = W.rhs_vector(m["nbrows"] * 4)
     d = O.jacobi_compute(m)
     ze, ye = O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL, return_y=True)
     zj = O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=np.zeros_like(r))
-    assert np.linalg.norm(vecs["z"] - ze) <= 1.05 * np.linalg.norm(zj - ze) + 1e-12 * np.linalg.norm(ze)
+    if sweep_mode is None:
+        assert rel(vecs["z"], zj) < 1e-12
+    else:
+        assert np.linalg.norm(vecs["z"] - ze) <= 1.05 * np.linalg.norm(zj - ze) + 1e-12 * np.linalg.norm(ze)
+
+
+def test_pcshell_default_is_a_fixed_operator(tmp_path):
+    """two runs of the default mode give bit-identical applications (what a non-flexible Krylov method needs),
+    and BLASTED_HIP_SWEEP_MODE is validated"""
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
+    _, v1, _ = run(tmp_path, opts, env=SYNC)   # synchronous factorisation as well: everything deterministic
+    _, v2, _ = run(tmp_path, opts, env=SYNC)
+    assert np.array_equal(v1["z"], v2["z"])
+    _, _, r = run(tmp_path, opts, env={"BLASTED_HIP_SWEEP_MODE": "bogus"}, expect_rc=3)
+    assert "BLASTED_HIP_SWEEP_MODE" in r.stderr
 
 
 @pytest.mark.parametrize("opts,kind", [
