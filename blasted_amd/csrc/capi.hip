@@ -1755,6 +1755,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
 			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;
+		else if (spec && std::strncmp(spec, "factor1=", 8) == 0)
+			set_factor1_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)

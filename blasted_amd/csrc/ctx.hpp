@@ -160,6 +160,9 @@ void build_natural_storage(const Pattern &pat, LevelSchedule &ns, hipStream_t s)
 void build_level_storage(const Pattern &pat, LevelSchedule &ls, hipStream_t s);
 void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, const double *vals,
                                  double *lvals, double *uvals, hipStream_t s);
+// kernels_factor1.hip (scalar CSR factorisation sweep with chunk-staged operands)
+bool launch_factor1(const FactorArgs &a, hipStream_t s);
+void set_factor1_enabled(int on);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
 void set_factor4_enabled(int on);

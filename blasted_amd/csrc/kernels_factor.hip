@@ -514,6 +514,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 {
 	if (a.pat.nbrows == 0)
 		return;
+	if (launch_factor1(a, s))
+		return;
 	if (launch_factor4(a, s))
 		return;
 	if (launch_factor8(a, a.dinv_scratch, s))

@@ -204,7 +204,8 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * slots per row at bs=4 -- 1 (default), 2, or 3 = one slot for the triangular sweeps only; u: row steps in
  * flight for the bs=4 triangular sweeps -- 1 (default; best accuracy per sweep) or 2 (2 % faster sweeps)); the same strings
  * are read once from the environment variable BLASTED_HIP_SWEEPW.  "factor4=0" / "factor4=1"
- * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4).
+ * switches the tuned bs=4 factorisation kernel off / on (environment: BLASTED_HIP_FACTOR4); "factor1=0" /
+ * "factor1=1" the chunk-staged scalar (CSR) factorisation kernel (BLASTED_HIP_FACTOR1).
  * "factorodd=0" / "factorodd=1": tuned bs=5/7 factorisation kernel off / on (BLASTED_HIP_FACTORODD).
  * "sweepwr=0" / "sweepwr=1": tuned row-major bs=4/8 sweep kernel off / on (BLASTED_HIP_SWEEPWR).
  * "sweepodd=0" / "sweepodd=1": tuned bs=3/5/7 sweep kernel off / on (environment: BLASTED_HIP_SWEEPODD).
