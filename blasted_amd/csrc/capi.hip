@@ -1729,6 +1729,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "levelserial=", 12) == 0)
+			set_level_serial_after(std::atol(spec + 12));
 		else if (spec && std::strncmp(spec, "levelstore=", 11) == 0)
 			g_level_store = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "level=", 6) == 0)

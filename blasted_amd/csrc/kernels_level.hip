@@ -78,6 +78,40 @@ __global__ __launch_bounds__(256) void level_relax_kernel(const Pattern pat, int
 		*changed = 1;
 }
 
+// The same fixed point by ONE wave walking the rows in order: row i's level is final once rows < i are, so one
+// pass is exact whatever the depth of the dependency graph -- O(nnz) work on a ~2 us dependent step per row.
+// The fall-back for patterns whose depth is of the order of the row count (banded, one-dimensional orderings),
+// on which the parallel passes above need one pass per level, i.e. O(nbrows * nnz) work.
+__global__ __launch_bounds__(64) void level_serial_kernel(const Pattern pat, int *level)
+{
+	const int lane = threadIdx.x;
+	for (int i = 0; i < pat.nbrows; i++) {
+		const int rbeg = pat.browptr[i], rend = pat.browptr[i + 1];
+		int m = __hip_atomic_load(&level[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (int jj = rbeg + lane; jj < rend; jj += 64) {
+			const int j = pat.bcolind[jj];
+			if (j < i) {
+				const int lj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				m = lj + 1 > m ? lj + 1 : m;
+			}
+		}
+		for (int off = 32; off > 0; off >>= 1) {
+			const int o = __shfl_xor(m, off, 64);
+			m = o > m ? o : m;
+		}
+		if (lane == 0)
+			__hip_atomic_store(&level[i], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (int jj = rbeg + lane; jj < rend; jj += 64) {
+			const int j = pat.bcolind[jj];
+			if (j > i)
+				atomicMax(&level[j], m + 1);
+		}
+		// this wave's own stores and atomics must be visible to its next iterations' loads
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+}
+
 __global__ __launch_bounds__(256) void iota_kernel(int *v, int n)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
@@ -606,6 +640,13 @@ T *lvl_alloc(size_t count)
 
 }  // namespace
 
+// tuning ("levelserial=N"): parallel relaxation passes of the level-schedule build before the in-order fall-back
+long g_level_serial_after = 4096;
+void set_level_serial_after(long n)
+{
+	g_level_serial_after = n > 0 ? n : 1;
+}
+
 void set_syncfree_one_step(int on)
 {
 	g_sf_one_step = on;
@@ -649,7 +690,9 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 		int hflags[BATCH];
 		bool fixed = false;
 		long passes = 0;
-		for (long done = 0; done < (long)n + 2 && !fixed; done += BATCH) {
+		// beyond this many passes (= dependency levels) the parallel relaxation loses to one in-order pass
+		const long serial_after = g_level_serial_after;
+		for (long done = 0; done < (long)n + 2 && !fixed && passes < serial_after; done += BATCH) {
 			BHIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * BATCH, s));
 			for (int q = 0; q < BATCH; q++)
 				hipLaunchKernelGGL(level_relax_kernel, dim3(grid), dim3(256), 0, s, pat, level, flags + q);
@@ -660,8 +703,13 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 				if (!hflags[q])
 					fixed = true;
 		}
-		if (!fixed)
-			BHIP_FAIL(BLASTED_HIP_ERUNTIME, "level schedule: dependency depths did not settle");
+		if (!fixed) {
+			// a deep dependency graph: finish with the in-order pass (exact after one sweep over the rows)
+			hipLaunchKernelGGL(level_serial_kernel, dim3(1), dim3(64), 0, s, pat, level);
+			BHIP_CHECK(hipGetLastError());
+			BHIP_CHECK(hipStreamSynchronize(s));
+			passes = -passes - 1;  // reported negative: "settled by the serial pass after that many parallel ones"
+		}
 		ls.build_passes = passes;
 
 		keys = lvl_alloc<int>(n);

@@ -132,6 +132,7 @@ static double dot(const std::vector<double> &a, const std::vector<double> &b)
 
 int main(int argc, char **argv)
 {
+	std::setvbuf(stdout, NULL, _IOLBF, 0);  // the report survives an abort further down
 	std::map<std::string, std::string> kv;
 	int i = 1;
 	for (; i + 1 < argc && std::strcmp(argv[i], "--") != 0; i += 2)

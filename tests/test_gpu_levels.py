@@ -82,6 +82,49 @@ def test_level_schedule_bit_exact(golden, case):
     p.close()
 
 
+@pytest.mark.parametrize("shape", ["chain", "one_sided_chain", "poisson"])
+def test_level_schedule_deep_graph_takes_the_in_order_pass(shape):
+    """A dependency graph about as deep as it is long (a banded, one-dimensional ordering: levels = rows) would
+    cost one parallel relaxation pass per level, O(nbrows * nnz) in all; after `levelserial` passes the build
+    finishes with ONE in-order pass instead.  Same levels, and the exact solves on it are the serial ones."""
+    if shape == "poisson":
+        m = W.poisson3d(12, 4)   # 28 levels: with the threshold at 8 the serial pass has to finish a 3-D pattern too
+    else:
+        n = 3000
+        rows = np.repeat(np.arange(n), 3)
+        cols = (rows.reshape(n, 3) + np.array([-1, 0, 1])).reshape(-1)
+        keep = (cols >= 0) & (cols < n)
+        if shape == "one_sided_chain":   # only the upper couplings are stored: the lower ones are implied
+            keep &= cols >= rows
+        rows, cols = rows[keep], cols[keep]
+        rp = np.zeros(n + 1, np.int32)
+        np.add.at(rp, rows + 1, 1)
+        rp = np.cumsum(rp).astype(np.int32)
+        rng = np.random.default_rng(5)
+        vals = rng.uniform(-0.3, 0.3, (rows.size, 4))
+        vals[rows == cols] = np.array([2.0, 0.1, -0.1, 2.5])
+        m = dict(nbrows=n, nnzb=int(rows.size), bs=2, rowmajor=False, browptr=rp, bcolind=cols.astype(np.int32),
+                 diagind=np.nonzero(rows == cols)[0].astype(np.int32), vals=np.ascontiguousarray(vals.reshape(-1)))
+    capi.set_tuning("levelserial=8")
+    try:
+        p = make_prec(m)
+        lv, rows_by_level, ptr = p.get_levels()
+        st = p.level_stats()
+    finally:
+        capi.set_tuning("levelserial=4096")
+    ref = W.dependency_levels(m)
+    assert np.array_equal(lv, ref)
+    assert st["build_passes"] < 0    # negative: settled by the serial pass after that many parallel ones
+    assert st["levels"] == ref.max() + 1
+    nvec = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(nvec)
+    p.ilu0_factorize(-1)
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(p.get_iluvals(), f) < TOL
+    assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)) < TOL
+    p.close()
+
+
 def test_level_schedule_nonsymmetric_pattern(golden):
     m = one_sided(W.poisson3d(10, 4))
     p = make_prec(m)

@@ -41,7 +41,31 @@ def main():
     zs_h = p.ilu0_apply(rh, s, mode=capi.JACOBI_SYNC)
     zs_d = p.ilu0_apply(rd, s, mode=capi.JACOBI_SYNC)
     assert np.array_equal(zs_h, zs_d.cpu().numpy())
+    # the same with the two host vectors page-locked in place (blasted_hip_host_register: the caller's choice)
+    capi.host_register(rh)
+    capi.host_register(zh)
+    tp = timed(lambda: p.ilu0_apply(rh, s, out=zh))
+    capi.host_unregister(rh)
+    capi.host_unregister(zh)
+    # set_values from host memory: a 4 GB slice of the value array, pageable and registered
+    nslice = min(m["vals"].numel(), 1 << 29)
+    vh = np.ones(nslice)
+    vd = torch.empty(nslice, dtype=torch.float64, device=dev)
+
+    import ctypes as C
+    capi.lib().blasted_hip_buffer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_ulong]
+
+    def upload():
+        capi._check(capi.lib().blasted_hip_buffer_upload(vd.data_ptr(), vh.ctypes.data, vh.nbytes))
+    tu = timed(upload, reps=3)
+    capi.host_register(vh)
+    tur = timed(upload, reps=3)
+    capi.host_unregister(vh)
     mb = 2 * nv * 8 / 1e6
+    print("host-vector apply with r and z page-locked (blasted_hip_host_register): %.2f ms = %.1f sweep pairs/s, "
+          "transfers %.2f ms = %.1f GB/s; value upload of %.1f GB: pageable %.1f GB/s, page-locked %.1f GB/s" % (
+              tp * 1e3, s / tp, (tp - td) * 1e3, mb / 1e3 / (tp - td), vh.nbytes / 1e9, vh.nbytes / 1e9 / tu,
+              vh.nbytes / 1e9 / tur))
     print("n=%d bs=%d napplysweeps=%d: device-resident apply %.2f ms = %.1f sweep pairs/s; host-vector apply "
           "%.2f ms = %.1f sweep pairs/s (PCIe-inclusive; %.0f MB moved, transfers %.2f ms = %.1f GB/s)" % (
               n, bs, s, td * 1e3, s / td, th * 1e3, s / th, mb, (th - td) * 1e3, mb / 1e3 / (th - td)))

@@ -69,12 +69,13 @@ def main():
         ("none", None, lambda v: v),
         ("jacobi", lambda: p.jacobi_compute(), lambda v: p.jacobi_apply(v)),
         ("sgs async 3 sweeps", lambda: p.jacobi_compute(), lambda v: p.sgs_apply(v, 3)),
+        ("sgs DETERMINISTIC 3 sweeps (host default)", lambda: p.jacobi_compute(), lambda v: p.sgs_apply(v, 3, mode=capi.DETERMINISTIC)),
         ("sgs exact (level_sgs)", lambda: p.jacobi_compute(), lambda v: p.sgs_apply(v, 1, mode=capi.LEVEL)),
         ("ilu0 async 3 build + 1 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1)),
         ("ilu0 async 3 build + 3 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 3)),
         ("ilu0 async 3 build + 10 apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 10)),
-        ("ilu0 async 3 build + 3 SYNCHRONOUS (Jacobi) apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 3, mode=capi.JACOBI_SYNC)),
-        ("ilu0 async 3 build + 10 SYNCHRONOUS (Jacobi) apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 10, mode=capi.JACOBI_SYNC)),
+        ("ilu0 async 3 build + 3 DETERMINISTIC apply sweeps (host default)", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 3, mode=capi.DETERMINISTIC)),
+        ("ilu0 async 3 build + 10 DETERMINISTIC apply sweeps", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 10, mode=capi.DETERMINISTIC)),
         ("sapilu0: async 3 build, exact apply", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
         ("seqilu0: exact build, exact apply", lambda: p.ilu0_factorize(-1), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
     ]
@@ -99,7 +100,7 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         true = float((b - A(x)).norm() / b.norm())
-        print("%-40s setup %7.1f ms  solve %8.1f ms  iterations %4d  residual %.1e (true %.1e)" % (
+        print("%-62s setup %7.1f ms  solve %8.1f ms  iterations %4d  residual %.1e (true %.1e)" % (
             name, (t1 - t0) * 1e3, (t2 - t1) * 1e3, its, res, true), flush=True)
     p.close()
 
