@@ -147,6 +147,95 @@ def test_empty_subdomain_is_a_no_op(bs):
     L.blasted_hip_destroy(h)
 
 
+def test_memory_stats_and_one_derived_copy_per_triangle():
+    """An operator that is applied both ways keeps each triangle of the factor in ONE derived ordering (the one
+    asked for last) unless copies=both; blasted_hip_memory_stats follows every allocation."""
+    m = W.poisson3d(14, 4)
+    n = m["nbrows"] * 4
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    base = p.memory_stats()
+    assert base["derived_copies"] == 0 and base["bytes"] >= m["vals"].nbytes   # pattern + value mirror
+    p.ilu0_factorize(3)
+    fbytes = m["vals"].nbytes
+    after_f = p.memory_stats()
+    assert after_f["bytes"] >= base["bytes"] + fbytes and after_f["derived_copies"] == 0
+    za = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)          # natural-order triangles
+    s1 = p.memory_stats()
+    assert s1["derived_copies"] == 2 and s1["bytes"] >= after_f["bytes"] + fbytes
+    ze = p.ilu0_apply(r, 1, mode=capi.LEVEL)                # level-ordered triangles replace them
+    s2 = p.memory_stats()
+    assert s2["derived_copies"] == 2
+    assert np.array_equal(za, p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC))   # and back: same result
+    assert p.memory_stats()["derived_copies"] == 2
+    capi.set_tuning("copies=both")
+    try:
+        p.ilu0_apply(r, 1, mode=capi.LEVEL)
+        assert p.memory_stats()["derived_copies"] == 4
+        assert np.array_equal(ze, p.ilu0_apply(r, 1, mode=capi.LEVEL))
+    finally:
+        capi.set_tuning("copies=one")
+    assert p.memory_stats()["peak_bytes"] >= p.memory_stats()["bytes"]
+    # the product-mode SGS application holds the level-ordered lower and the natural-order upper triangle
+    q = make_prec(m)
+    q.jacobi_compute()
+    q.sgs_apply(r, 2, mode=capi.DETERMINISTIC)
+    assert q.memory_stats()["derived_copies"] == 2
+    q.close()
+    p.close()
+
+
+def test_host_register_is_explicit_and_checked():
+    """blasted_hip_host_register page-locks a caller-owned range for the host-vector entry points; results are
+    the same with and without it, double registration and unknown addresses are refused."""
+    m = W.poisson3d(40, 4)          # 2.0 MB vectors
+    n = m["nbrows"] * 4
+    r = W.rhs_vector(n)
+    z = np.zeros(n)
+    p = make_prec(m)
+    p.ilu0_factorize(-1)
+    want = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+    capi.host_register(r)
+    capi.host_register(z)
+    assert p.memory_stats()["pinned_host_bytes"] >= r.nbytes + z.nbytes
+    with pytest.raises(capi.BlastedHipError) as ei:
+        capi.host_register(r)
+    assert ei.value.code == capi.ESTATE
+    got = p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z)
+    assert np.array_equal(got, want)
+    capi.host_unregister(r)
+    capi.host_unregister(z)
+    with pytest.raises(capi.BlastedHipError):
+        capi.host_unregister(z)
+    assert p.memory_stats()["pinned_host_bytes"] == 0
+    assert np.array_equal(p.ilu0_apply(r, 1, mode=capi.LEVEL), want)
+    p.close()
+
+
+@pytest.mark.parametrize("bs", [1, 4, 5, 8])
+def test_xcd_super_chunk_size_does_not_change_results(bs):
+    """the run-time super-chunk size of the XCD-aware chunk numbering only reorders workgroups: synchronous
+    sweeps are bit-identical for every value, and bad values are rejected"""
+    m = W.poisson3d(20, bs)
+    r = W.rhs_vector(m["nbrows"] * bs)
+    p = make_prec(m)
+    p.ilu0_factorize(2, mode=capi.JACOBI_SYNC)
+    ref = None
+    try:
+        for x in (16, 1, 4, 64, 4096):
+            capi.set_tuning("xcdsuper=%d" % x)
+            z = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+            y = p.spmv(r)
+            if ref is None:
+                ref = (z, y)
+            assert np.array_equal(z, ref[0]) and np.array_equal(y, ref[1])
+        with pytest.raises(capi.BlastedHipError):
+            capi.set_tuning("xcdsuper=12")
+    finally:
+        capi.set_tuning("xcdsuper=16")
+    p.close()
+
+
 def test_measure_read_stream_reports_a_plausible_rate():
     """The measurement aid behind bench.py's roofline.measured_read_stream_gbps: a 256 MB buffer streams at
     well above 1 TB/s and below the 8 TB/s peak; misaligned and null buffers are rejected."""

@@ -40,11 +40,20 @@ def main():
         tune = {k: int(rng.integers(0, 2)) for k in ("levelstore", "levelwide", "levelperm", "compact",
                                                      "interleave", "sweepodd", "sweepwr", "factorodd",
                                                      "factor4", "factor8", "gunroll")}
+        tune["factor1"] = int(rng.integers(0, 2))
         tune["level"] = str(rng.choice(["syncfree", "syncfree", "launch"]))
+        tune["copies"] = str(rng.choice(["one", "both"]))
+        tune["xcdsuper"] = int(rng.choice([1, 4, 16, 64]))
+        tune["levelserial"] = int(rng.choice([4096, 4096, 8]))   # 8: the in-order fall-back of the level build
         for k, v in tune.items():
             capi.set_tuning("%s=%s" % (k, v))
+        if tune["sweepodd"]:
+            tune["sweepodd_nt"] = str(rng.choice(["nt0", "nt1"]))
+            tune["sweepodd_occ"] = str(rng.choice(["occ0", "occ1"]))
+            capi.set_tuning("sweepodd=" + tune["sweepodd_nt"])
+            capi.set_tuning("sweepodd=" + tune["sweepodd_occ"])
         tune["sweepw"] = str(rng.choice(["generic", "r128,nt1,u2,s1", "r128,nt0,u2,s2", "r128,nt1,u1,s3",
-                                         "r256,nt1,u2,s1", "r256,nt0,u1,s2"]))
+                                         "r256,nt1,u2,s1", "r256,nt0,u1,s2", "r128,nt1,u1,s1", "r128,nt1,u1,s1,c1"]))
         capi.set_tuning(tune["sweepw"])
         case = dict(it=it, bs=bs, nb=nb, rowmajor=rm, avg_offdiag=dens, scaling=sc, tune=tune)
         m = W.random_bsr(nb, bs, avg_offdiag=dens, seed=int(rng.integers(1, 1 << 30)), rowmajor=rm)
@@ -85,7 +94,17 @@ def main():
         d = p.get_dblocks()
         check("jacobi", p.jacobi_apply(r), O.jacobi_apply(m, d, r), 1e-12)
         check("sgs_sync", p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC), O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC), 1e-10)
-        check("sgs_exact", p.sgs_apply(r, 1, mode=capi.LEVEL), O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL), 1e-9)
+        zs, ys = O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL, return_y=True)
+        check("sgs_exact", p.sgs_apply(r, 1, mode=capi.LEVEL), zs, 1e-9)
+        if np.all(np.isfinite(zs)) and np.abs(zs).max() < 1e8:
+            # the product modes: exact forward half; deterministic = synchronous backward sweeps from it
+            check("sgs_determ", p.sgs_apply(r, 2, mode=capi.DETERMINISTIC),
+                  O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ys, z0=np.zeros(n)), 1e-9)
+            p.sgs_apply(r, 1, mode=capi.ASYNC)
+            check("sgs_async_fwd", p.get_ytemp(), ys, 1e-9)
+            check("sgs_async", p.sgs_apply(r, p.level_count() + 2, mode=capi.ASYNC), zs, 1e-8)
+        ms = p.memory_stats()
+        assert ms["bytes"] > 0 and ms["peak_bytes"] >= ms["bytes"] and (tune["copies"] == "both" or ms["derived_copies"] <= 4), (ms, case)  # (<= 2 triangles each of factor and matrix)
         xr = O.sgs_relax(m, d, r, x0=x0, maxits=2, mode=O.GS_SERIAL)
         if np.all(np.isfinite(xr)) and np.abs(xr).max() < 1e8:
             check("relax_exact", p.sgs_relax(r, x0.copy(), 2, mode=capi.LEVEL), xr, 1e-9)
@@ -99,8 +118,8 @@ def main():
         assert p.level_stats()["syncfree_aborts"] == 0, case
         p.close()
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
-                 "sweepodd=1", "sweepwr=1", "factorodd=1", "factor4=1", "factor8=1", "gunroll=0",
-                 "r128,nt1,u1,s1"):
+                 "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
+                 "factor8=1", "gunroll=0", "copies=one", "xcdsuper=16", "levelserial=4096", "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
     for k in sorted(worst):
