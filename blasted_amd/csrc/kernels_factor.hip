@@ -256,7 +256,10 @@ __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat
                                                                const int nlist)
 {
 	constexpr int BS2 = BS * BS, LD = BS2 + 1;  // +1: conflict-free strided LDS reads
-	__shared__ double tile[64 * LD];
+	// bs 7 / 8: the transpose goes through LDS in two halves of 32 blocks (16.6 KB instead of 33 KB per 64
+	// threads: the 160-215 VGPRs then bound the occupancy -- 8 to 12 waves per CU -- instead of LDS at 4 to 6)
+	constexpr int NH = BS >= 7 ? 2 : 1, HB = 64 / NH;
+	__shared__ double tile[HB * LD];
 	const int t = threadIdx.x;
 	const long total = rows ? nlist : pat.nbrows;  // optional row list (level-scheduled factorisation)
 	const long row0 = (long)blockIdx.x * 64;
@@ -266,27 +269,31 @@ __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat
 	const long sblk = src_by_diag ? dgpos : myrow, dblk = dst_by_diag ? dgpos : myrow;
 	const int nrows = (total - row0) < 64 ? (int)(total - row0) : 64;
 
-	// HBM -> LDS, one block per wave instruction
-	for (int i = 0; i < nrows; i++) {
-		const long blk = __shfl(sblk, i, 64);
-		if (t < BS2)
-			tile[i * LD + t] = src[blk * BS2 + t];
-	}
-	__syncthreads();
-
 	double m[BS][BS];
-	if (rowok) {
 #pragma unroll
-		for (int r = 0; r < BS; r++)
+	for (int r = 0; r < BS; r++)
 #pragma unroll
-			for (int c = 0; c < BS; c++)
-				m[r][c] = tile[t * LD + (RM ? r * BS + c : c * BS + r)];
-	} else {
+		for (int c = 0; c < BS; c++)
+			m[r][c] = (r == c) ? 1.0 : 0.0;
+	// HBM -> LDS, one block per wave instruction; every thread picks its own block up from the tile
 #pragma unroll
-		for (int r = 0; r < BS; r++)
+	for (int h = 0; h < NH; h++) {
+		const int iend = nrows < (h + 1) * HB ? nrows : (h + 1) * HB;
+		for (int i = h * HB; i < iend; i++) {
+			const long blk = __shfl(sblk, i, 64);
+			if (t < BS2)
+				tile[(i - h * HB) * LD + t] = src[blk * BS2 + t];
+		}
+		__syncthreads();
+		if (rowok && t / HB == h) {
 #pragma unroll
-			for (int c = 0; c < BS; c++)
-				m[r][c] = (r == c) ? 1.0 : 0.0;
+			for (int r = 0; r < BS; r++)
+#pragma unroll
+				for (int c = 0; c < BS; c++)
+					m[r][c] = tile[(t - h * HB) * LD + (RM ? r * BS + c : c * BS + r)];
+		}
+		if (NH > 1)
+			__syncthreads();
 	}
 
 	// in-place Gauss-Jordan with partial pivoting; piv[p] = row swapped with p at step p
@@ -347,15 +354,23 @@ __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat
 
 	__syncthreads();
 #pragma unroll
-	for (int r = 0; r < BS; r++)
+	for (int h = 0; h < NH; h++) {
+		if (t / HB == h) {
 #pragma unroll
-		for (int c = 0; c < BS; c++)
-			tile[t * LD + (RM ? r * BS + c : c * BS + r)] = m[r][c];
-	__syncthreads();
-	for (int i = 0; i < nrows; i++) {
-		const long blk = __shfl(dblk, i, 64);
-		if (t < BS2)
-			dst[blk * BS2 + t] = tile[i * LD + t];
+			for (int r = 0; r < BS; r++)
+#pragma unroll
+				for (int c = 0; c < BS; c++)
+					tile[(t - h * HB) * LD + (RM ? r * BS + c : c * BS + r)] = m[r][c];
+		}
+		__syncthreads();
+		const int iend = nrows < (h + 1) * HB ? nrows : (h + 1) * HB;
+		for (int i = h * HB; i < iend; i++) {
+			const long blk = __shfl(dblk, i, 64);
+			if (t < BS2)
+				dst[blk * BS2 + t] = tile[(i - h * HB) * LD + t];
+		}
+		if (NH > 1)
+			__syncthreads();
 	}
 }
 
