@@ -896,7 +896,19 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 			// dependent lower block, no inversion pass at the end) -- unless the remainder, which is defined
 			// on the un-inverted factor, is asked for
 			fa.diag_inverted = (pat.bs > 1 && !precinfo) ? 1 : 0;
-			ph.launches = launch_factor_levels(fa, need_levels(p), p->stream);
+			LevelSchedule &ls = need_levels(p);
+			// one launch whose rows wait for their predecessors, so that levels overlap ("level=launch" keeps one
+			// launch per level, as for the exact solves)
+			const int sf = g_level_impl == 0 ? launch_factor_syncfree(fa, ls, p->stream) : 0;
+			if (sf != 0)
+				ls.sf_launches++;
+			if (sf == 1)
+				ph.launches = 2;
+			else {
+				if (sf < 0)
+					ls.sf_aborts++;  // a wave gave up waiting: redone with one launch per level
+				ph.launches = launch_factor_levels(fa, ls, p->stream);
+			}
 			ph.done();
 		} else {
 			Phase ph(p, 0);
@@ -1757,6 +1769,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
 			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;
+		else if (spec && std::strncmp(spec, "factorsf=", 9) == 0)
+			set_factor_syncfree(spec[9] - '0');
 		else if (spec && std::strncmp(spec, "factor1=", 8) == 0)
 			set_factor1_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)

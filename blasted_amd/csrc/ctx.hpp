@@ -176,6 +176,8 @@ void set_factorodd_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);
+int launch_factor_syncfree(const FactorArgs &a, const LevelSchedule &ls, hipStream_t s);
+void set_factor_syncfree(int on);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,
                                double *dst, long dst_is_indexed_by_diag, hipStream_t s);
 void launch_fact_init(const Pattern &pat, const double *avals, const double *scale, int init_type,

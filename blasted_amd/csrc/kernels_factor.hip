@@ -547,6 +547,177 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s)
 	BHIP_CHECK(hipGetLastError());
 }
 
+// ---- the exact factorisation as ONE launch ---------------------------------------------------------------
+// Round 2 measured that a level of the per-level form below costs one wave-lifetime of mostly idle chip, 766
+// times at 256^3, and that storage order has nothing to do with it (tools/probes/level_ordered_factor.py).  This
+// is the form the exact solves already have (kernels_level.hip): one launch, rows taken in level order by
+// increasing workgroup id, and a row WAITS for the rows it depends on instead of a launch boundary, so that the
+// levels overlap.  What a row reads from other rows are blocks of their diagonal + upper part (the u_kj of its
+// position pairs and the inverted diagonal block of each lower entry's column); those blocks are pre-filled
+// with the "pending" NaN pattern and published entry by entry with 8-byte agent-scope stores, so every entry is
+// its own ready flag: a reader looks through the caches first (an entry is written once after the fill: anything
+// but "pending" is final wherever it is read from) and re-reads coherently only what is still pending.  No
+// fences, no flag array.  A lane group never blocks -- the rows of one wave may depend on each other across a
+// level boundary -- it retries its current entry in the wave's next round; spins are bounded, a wave that runs
+// out raises the abort flag and the host redoes the factorisation level by level.
+constexpr unsigned long long SFF_PENDING = 0xFFF8DEADBEEF0001ull;  // = SF_PENDING of kernels_level.hip
+constexpr int SFF_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ bool sff_pending(const double v)
+{
+	return (unsigned long long)__double_as_longlong(v) == SFF_PENDING;
+}
+
+// value of *p, through the caches first and coherently if that still shows the fill pattern
+__device__ __forceinline__ double sff_read(const double *p)
+{
+	double v = *p;
+	if (sff_pending(v))
+		v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+		                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	return v;
+}
+
+__device__ __forceinline__ void sff_publish(double *p, const double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the diagonal + upper blocks of every row <- "pending" (16 lanes per row)
+template <int BS>
+__global__ __launch_bounds__(256) void sff_fill_kernel(const Pattern pat, double *f)
+{
+	const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+	if (row >= pat.nbrows)
+		return;
+	const long beg = (long)pat.diagind[row] * (BS * BS), end = (long)pat.browptr[row + 1] * (BS * BS);
+	unsigned long long *const q = reinterpret_cast<unsigned long long *>(f);
+	for (long k = beg + (threadIdx.x & 15); k < end; k += 16)
+		q[k] = SFF_PENDING;
+}
+
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void sff_factor_kernel(const FactorArgs a, const int4 *__restrict__ meta,
+                                                         const int count, int *ctl)
+{
+	using Ge = FGeo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
+	constexpr unsigned long long GMASK = SUB == 64 ? ~0ull : ((1ull << SUB) - 1ull);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / SUB, u = lane % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(SUB - 1);
+
+	const long pos = (long)blockIdx.x * Ge::RPB + wave * Ge::RPW + g;  // position in level order
+	const bool rowok = pos < count;
+	const int4 md = rowok ? meta[pos] : make_int4(0, 0, 0, 0);  // {row, browptr, diagind, browptr of the next row}
+	const int irow = md.x;
+	int jpos = rowok ? md.y : 0;
+	const int jend = rowok ? md.w : 0;
+	double *const f = a.out;  // in place: a.in == a.out
+
+	int spins = 0;
+	for (;;) {
+		const bool busy = jpos < jend;
+		if (__builtin_amdgcn_ballot_w64(busy) == 0ull)
+			return;
+		if (busy) {
+			// one attempt at entry jpos of this group's row; `ready` drops when an operand is still pending
+			const int col = a.pat.bcolind[jpos];
+			double s = active ? a.avals[(long)jpos * BS2 + e] : 0.0;
+			if (a.scale && active) {
+				if (BS == 1)
+					s *= a.scale[irow] * a.scale[col];
+				else
+					s *= a.scale[(long)irow * BS + r] * a.scale[(long)col * BS + c];
+			}
+			bool ready = true;
+			const int kbeg = a.posptr[jpos], kend = a.posptr[jpos + 1];
+			for (int k = kbeg; k < kend; k++) {
+				// l_ik: a lower block of this row, stored by this group earlier in this launch
+				const double lv = active ? f[(long)a.lowerp[k] * BS2 + e] : 0.0;
+				const double uv = active ? sff_read(f + (long)a.upperp[k] * BS2 + e) : 0.0;
+				ready = ready && !sff_pending(uv);
+				if (BS == 1)
+					s -= lv * uv;
+				else
+					s -= group_gemm<BS, BSP>(lv, uv, gbase, r, c);
+			}
+			double dv = 0.0;
+			if (irow > col) {
+				dv = active ? sff_read(f + (long)a.pat.diagind[col] * BS2 + e) : 0.0;
+				ready = ready && !sff_pending(dv);
+			}
+			// the whole lane group commits or retries together
+			const unsigned long long rb = __builtin_amdgcn_ballot_w64(ready);
+			const bool gready = ((rb >> gbase) & GMASK) == GMASK;
+			if (gready) {
+				if (irow > col) {
+					// diagonal blocks are stored inverted (bs > 1); the scalar factor keeps u_jj itself
+					const double res = (BS == 1) ? s / dv : group_gemm<BS, BSP>(s, dv, gbase, r, c);
+					if (active)
+						f[(long)jpos * BS2 + e] = res;
+				} else if (irow == col && BS > 1) {
+					const double inv = group_inverse<BS, BSP>(s, gbase, r, c);
+					if (active)
+						sff_publish(f + (long)jpos * BS2 + e, inv);
+				} else if (active) {
+					sff_publish(f + (long)jpos * BS2 + e, s);
+				}
+				jpos++;
+			}
+		}
+		spins++;
+		if (spins > SFF_SPIN_LIMIT ||
+		    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+	}
+}
+
+static int g_factor_syncfree = 1;  // tuning "factorsf=0|1|2": one launch per level | one launch where it pays | always one launch
+void set_factor_syncfree(int on)
+{
+	g_factor_syncfree = on;
+}
+
+// The exact factorisation as one launch: 1 = done, 0 = does not apply, -1 = a wave gave up waiting (the caller
+// then runs launch_factor_levels, which does not depend on what this attempt left behind).
+int launch_factor_syncfree(const FactorArgs &a, const LevelSchedule &ls, hipStream_t s)
+{
+	if (!g_factor_syncfree || !ls.built || !ls.meta || !ls.ctl || a.in != a.out || a.pat.nbrows == 0)
+		return 0;
+	if (a.pat.bs > 1 && !a.diag_inverted)
+		return 0;  // (the remainder diagnostics want the un-inverted factor: per-level form)
+	// Where it pays (round 2, ms per exact factorisation, one launch per level -> one launch):
+	//   bs=8 100^3 7.96 -> 5.58, bs=7 128^3 11.75 -> 9.54, unstructured bs=5 (1006 levels) 32.6 -> 15.5,
+	//   bs=4 256^3 20.0 -> 18.5, bs=4 128^3 5.85 -> 5.99, bs=3 128^3 5.74 -> 6.30, bs=2 128^3 5.60 -> 19.5,
+	//   scalar 64^3 2.54 -> 12.3.
+	// A lane group that had to retry is out of phase with the other groups of its wave for the rest of its row
+	// (its entries have other pair counts than theirs), so the more rows share a wave -- 4 at bs=4, 16 at bs=2, 64
+	// for scalars -- the more of each round runs on a fraction of the lanes.  The default takes the single launch
+	// where a wave is one row (bs >= 5); "factorsf=2" forces it for every block size (tests).
+	if (g_factor_syncfree < 2 && a.pat.bs < 5)
+		return 0;
+	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+	BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
+		const unsigned fgrid = (unsigned)(((long)a.pat.nbrows + 15) / 16);
+		hipLaunchKernelGGL((sff_fill_kernel<BS>), dim3(fgrid), dim3(256), 0, s, a.pat, a.out);
+		const unsigned grid = (unsigned)(((long)ls.count + FGeo<BS>::RPB - 1) / FGeo<BS>::RPB);
+		hipLaunchKernelGGL((sff_factor_kernel<BS, RM>), dim3(grid), dim3(256), 0, s, a, ls.meta, ls.count, ls.ctl);
+	})
+	BHIP_CHECK(hipGetLastError());
+	int ctl[2] = {0, 0};
+	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	return ctl[1] == 0 ? 1 : -1;
+}
+
 // Exact ILU(0) in one pass (the reference's sequential factorisation, threadedfactor = false: one
 // in-order sweep, src/async_blockilu_factor.cpp:186-204 with one thread): one launch per dependency
 // level over that level's rows, in place.  A row's entries need final values of rows in earlier levels
@@ -575,7 +746,10 @@ int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s)
 	// row per block slot, the row's finished lower blocks kept in LDS: 19.96 ms against 20.2 ms.  Neither the
 	// dependent chain nor the block arithmetic bounds a level; its rows are scattered over the natural-order
 	// storage (a wavefront i+j+k = const), every operand is a lone 128-byte access, and ~2.2 TB/s is what that
-	// pattern gets.  A level-ordered copy of the factor *and* its position lists would be the lever.)
+	// pattern gets.  -- Round 2 measured that conclusion away: on the matrix symmetrically permuted into its own
+	// level order, where every level's rows, blocks and gather targets are contiguous, this same loop takes 19.0 ms
+	// instead of 20.1 (tools/probes/level_ordered_factor.py).  A level costs one wave-lifetime of mostly idle chip,
+	// 766 times; the lever is overlapping levels inside one launch, as the exact solves do.)
 	// (Tried: the 766 launches of the 256^3 problem as one instantiated hipGraph.  On a private stream the
 	// level loop takes 22.0 ms instead of ~23.7 ms -- the kernels themselves are 21.4 ms, the rest of the
 	// 29.6 ms call is the initial copy of the values and the final inversion of the diagonal blocks -- and

@@ -125,6 +125,28 @@ def test_level_schedule_deep_graph_takes_the_in_order_pass(shape):
     p.close()
 
 
+@pytest.mark.parametrize("case", CASES + ["poisson9_bs8", "random_bs5", "poisson8_bs7_row"])
+def test_exact_factorisation_single_launch_equals_per_level(golden, case):
+    """The exact factorisation as ONE launch whose rows wait for the rows they depend on (factorsf) is the same
+    arithmetic in the same order as one launch per level: bit-identical factors, for every block size and layout
+    (the default uses it where a wave is one row, bs >= 5; factorsf=2 forces it everywhere)."""
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    res = {}
+    try:
+        for k in ("0", "2", "1"):
+            capi.set_tuning("factorsf=" + k)
+            p.ilu0_factorize(-1)
+            res[k] = p.get_iluvals()
+    finally:
+        capi.set_tuning("factorsf=1")
+    assert np.array_equal(res["0"], res["2"]) and np.array_equal(res["0"], res["1"])
+    assert p.level_stats()["syncfree_aborts"] == 0
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(res["2"], f) < TOL
+    p.close()
+
+
 def test_level_schedule_nonsymmetric_pattern(golden):
     m = one_sided(W.poisson3d(10, 4))
     p = make_prec(m)
