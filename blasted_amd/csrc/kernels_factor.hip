@@ -698,10 +698,16 @@ int launch_factor_syncfree(const FactorArgs &a, const LevelSchedule &ls, hipStre
 	//   bs=8 100^3 7.96 -> 5.58, bs=7 128^3 11.75 -> 9.54, unstructured bs=5 (1006 levels) 32.6 -> 15.5,
 	//   bs=4 256^3 20.0 -> 18.5, bs=4 128^3 5.85 -> 5.99, bs=3 128^3 5.74 -> 6.30, bs=2 128^3 5.60 -> 19.5,
 	//   scalar 64^3 2.54 -> 12.3.
-	// A lane group that had to retry is out of phase with the other groups of its wave for the rest of its row
-	// (its entries have other pair counts than theirs), so the more rows share a wave -- 4 at bs=4, 16 at bs=2, 64
-	// for scalars -- the more of each round runs on a fraction of the lanes.  The default takes the single launch
-	// where a wave is one row (bs >= 5); "factorsf=2" forces it for every block size (tests).
+	// It pays where the per-level form suffers most from its launch boundaries (deep, narrow level structures; one
+	// row per wave) and loses where many rows share a wave.  Not because of divergence between lane groups that got
+	// out of phase: a form of the round that is executed in lockstep by the whole wave (wave-maximum loop bounds,
+	// selects instead of branches, every group computing the product with the inverse and -- when any group is at
+	// its diagonal -- the inverse) was built and was slower everywhere (bs=8 5.6 -> 7.0 ms, unstructured 15.9 ->
+	// 17.4, bs=4 256^3 18.5 -> 20.5).  The rows of a wave sit in one level and wait for the previous one together;
+	// this kernel asks for a row's operands entry by entry, so a waiting row has nothing else in flight -- unlike
+	// the exact solves, which request everything independent up front.  That form (a row's indices and A blocks
+	// staged at the start, polls only for the dependent operands) is what the headline bs=4 case would need.
+	// The default takes the single launch where a wave is one row (bs >= 5); "factorsf=2" forces it everywhere (tests).
 	if (g_factor_syncfree < 2 && a.pat.bs < 5)
 		return 0;
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
