@@ -100,6 +100,10 @@ struct LevelSchedule {
 	int *lcolp = nullptr, *ucolp = nullptr;    // device: lcol / ucol mapped through posof
 	int4 *lheadp = nullptr, *uheadp = nullptr; // device, 2 * nbrows: lhead / uhead mapped through posof
 	long nnz_lower = 0, nnz_dupper = 0;
+	// single-launch exact factorisation at bs = 4 (kernels_factor4.hip): longest pair list of a row (-1: not looked
+	// at yet), per-level workgroup layout
+	int f4_maxpairs = -1, f4_grid = 0;
+	int2 *f4_wgpos = nullptr;  // device, per workgroup: its range of positions in level order
 };
 
 // Arrays a single-launch pass reads instead of the natural-order ones (level-ordered copies)
@@ -176,7 +180,9 @@ void set_factorodd_enabled(int on);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);
-int launch_factor_syncfree(const FactorArgs &a, const LevelSchedule &ls, hipStream_t s);
+int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s);
+int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s);
+void launch_factor_pending_fill(const Pattern &pat, double *f, hipStream_t s);
 void set_factor_syncfree(int on);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,
                                double *dst, long dst_is_indexed_by_diag, hipStream_t s);

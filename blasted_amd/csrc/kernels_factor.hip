@@ -680,20 +680,38 @@ __global__ __launch_bounds__(256) void sff_factor_kernel(const FactorArgs a, con
 	}
 }
 
-static int g_factor_syncfree = 1;  // tuning "factorsf=0|1|2": one launch per level | one launch where it pays | always one launch
+// tuning "factorsf=0|1|2|3": one launch per level | one launch where it pays | always one launch | always one
+// launch of the general kernel (no matrix-core kernel at bs = 4: bit-identical to the per-level form)
+static int g_factor_syncfree = 1;
 void set_factor_syncfree(int on)
 {
 	g_factor_syncfree = on;
 }
 
+// diagonal + upper blocks of the factor <- the pending pattern (before a single-launch exact factorisation)
+void launch_factor_pending_fill(const Pattern &pat, double *f, hipStream_t s)
+{
+	BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
+		(void)RM;
+		const unsigned fgrid = (unsigned)(((long)pat.nbrows + 15) / 16);
+		hipLaunchKernelGGL((sff_fill_kernel<BS>), dim3(fgrid), dim3(256), 0, s, pat, f);
+	})
+}
+
 // The exact factorisation as one launch: 1 = done, 0 = does not apply, -1 = a wave gave up waiting (the caller
 // then runs launch_factor_levels, which does not depend on what this attempt left behind).
-int launch_factor_syncfree(const FactorArgs &a, const LevelSchedule &ls, hipStream_t s)
+int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
 {
 	if (!g_factor_syncfree || !ls.built || !ls.meta || !ls.ctl || a.in != a.out || a.pat.nbrows == 0)
 		return 0;
 	if (a.pat.bs > 1 && !a.diag_inverted)
 		return 0;  // (the remainder diagnostics want the un-inverted factor: per-level form)
+	if (g_factor_syncfree != 3 && a.pat.bs == 4 && !a.pat.rowmajor) {
+		// stencil-like rows at bs = 4: the matrix-core kernel that prepares a row before it waits
+		const int r4 = launch_factor4_syncfree(a, ls, s);
+		if (r4 != 0)
+			return r4;
+	}
 	// Where it pays (round 2, ms per exact factorisation, one launch per level -> one launch):
 	//   bs=8 100^3 7.96 -> 5.58, bs=7 128^3 11.75 -> 9.54, unstructured bs=5 (1006 levels) 32.6 -> 15.5,
 	//   bs=4 256^3 20.0 -> 18.5, bs=4 128^3 5.85 -> 5.99, bs=3 128^3 5.74 -> 6.30, bs=2 128^3 5.60 -> 19.5,

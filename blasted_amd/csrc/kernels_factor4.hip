@@ -27,6 +27,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 namespace bhip {
 
@@ -164,9 +166,235 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 	}
 }
 
+// ---- the exact factorisation as one launch, bs = 4 (round 2) ------------------------------------------------
+// The general single-launch kernel (sff_factor_kernel, kernels_factor.hip) asks for a row's operands entry by
+// entry; what bounds the exact factorisation is the chain of dependency levels (766 at 256^3), each of which then
+// costs a row's whole walk.  Here a row is prepared BEFORE it waits: its column indices, position-list pointers
+// and pairs, the diagonal positions of its lower entries' columns, and all its operand blocks -- the A blocks and
+// the (possibly still pending) blocks of other rows -- are requested up front into registers, in matrix-core
+// operand layout.  What remains between "my predecessors have published" and "I have published" is a coherent
+// re-read of what was pending, the products and the inverse on registers, and the stores.
+// One wave = four block slots = four rows of ONE level (workgroups are laid out per level, so that the rows of a
+// wave never depend on each other and the wave can walk its entries in lockstep, q = 0, 1, ... with compile-time
+// register indices).  For stencil-like rows only: at most X4_MAXE entries, X4_MAXL of them lower, X4_MAXP position
+// pairs per row; other patterns take the general kernel.
+constexpr int X4_MAXE = 8, X4_MAXL = 4, X4_MAXP = 8;
+constexpr unsigned long long X4_PENDING = 0xFFF8DEADBEEF0001ull;  // = SFF_PENDING (kernels_factor.hip)
+constexpr int X4_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ bool x4_pending(const double v)
+{
+	return (unsigned long long)__double_as_longlong(v) == X4_PENDING;
+}
+
+__device__ __forceinline__ double x4_coherent(const double *p)
+{
+	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+	                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ void x4_publish(double *p, const double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, const int4 *__restrict__ meta,
+                                                        const int2 *__restrict__ wgpos, int *ctl)
+{
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int k = lane >> 4, b = (lane >> 2) & 3, m = lane & 3;
+	const int b4 = 4 * b;
+	const int t = 4 * k + m;     // index of this lane inside its block slot
+	const int offA = k * 4 + m;  // element (r = m, c = k)
+	const int offD = m * 4 + k;  // element (r = k, c = m)
+	double *const f = a.out;
+
+	// this workgroup's rows: positions [wp.x, wp.y) of the level order, all of one level
+	const int2 wp = wgpos[blockIdx.x];
+	const int pos = wp.x + wave * 4 + b;
+	const bool rowok = pos < wp.y;
+	const int4 md = rowok ? meta[pos] : make_int4(0, 0, 0, 0);  // {row, browptr, diagind, browptr of the next row}
+	const int irow = md.x, jbeg = md.y;
+	const int ne = rowok ? md.w - md.y : 0, nl = rowok ? md.z - md.y : 0;
+#define X4_SLOTLANE(Q) (16 * ((Q) >> 2) + b4 + ((Q) & 3))
+
+	// ---- indices of the row, one entry / pair per lane of the slot
+	const int colr = (t < ne) ? a.pat.bcolind[jbeg + t] : 0;
+	const int ppr = (rowok && t <= ne) ? a.posptr[jbeg + t] : 0;
+	const int pbeg = __shfl(ppr, X4_SLOTLANE(0), 64);
+	const int np = __shfl(ppr, X4_SLOTLANE(ne), 64) - pbeg;
+	const int lpr = (t < np) ? a.lowerp[pbeg + t] : 0;
+	const int upr = (t < np) ? a.upperp[pbeg + t] : 0;
+	const int dposr = (t < nl) ? a.pat.diagind[colr] : 0;
+
+	// ---- operands, in operand layout; blocks of other rows may still show the fill pattern
+	double aS[X4_MAXE], uvD[X4_MAXP], dvB[X4_MAXL];
+#pragma unroll
+	for (int q = 0; q < X4_MAXE; q++) {
+		const bool lowerq = q < nl;
+		aS[q] = (q < ne) ? a.avals[(long)(jbeg + q) * 16 + (lowerq ? offA : offD)] : 0.0;
+		if (a.scale && q < ne) {
+			const int cq = __shfl(colr, X4_SLOTLANE(q), 64);
+			const int r = lowerq ? m : k, c = lowerq ? k : m;  // (r,c) of this lane's entry: D layout (k,m), transposed (m,k)
+			aS[q] *= a.scale[(long)irow * 4 + r] * a.scale[(long)cq * 4 + c];
+		}
+	}
+	// (lane exchanges are kept out of divergent code and out of the waiting loops: a lane that is switched off hands
+	// out nothing, and an exchange costs about as much as a cache hit)
+	int upo[X4_MAXP], dpo[X4_MAXL];
+#pragma unroll
+	for (int tt = 0; tt < X4_MAXP; tt++) {
+		upo[tt] = __shfl(upr, X4_SLOTLANE(tt), 64);
+		uvD[tt] = (tt < np) ? f[(long)upo[tt] * 16 + offD] : 0.0;
+	}
+#pragma unroll
+	for (int q = 0; q < X4_MAXL; q++) {
+		dpo[q] = __shfl(dposr, X4_SLOTLANE(q), 64);
+		dvB[q] = (q < nl) ? f[(long)dpo[q] * 16 + offD] : 0.0;
+	}
+	// pair tt: 4 * (the entry it belongs to; 8 = none) + the lower entry of this row it multiplies
+	int pcode[X4_MAXP];
+#pragma unroll
+	for (int tt = 0; tt < X4_MAXP; tt++)
+		pcode[tt] = 32 + ((__shfl(lpr, X4_SLOTLANE(tt), 64) - jbeg) & 3);
+#pragma unroll
+	for (int q = 0; q < X4_MAXE; q++) {
+		const int tb = __shfl(ppr, X4_SLOTLANE(q), 64) - pbeg, te = __shfl(ppr, X4_SLOTLANE(q + 1), 64) - pbeg;
+#pragma unroll
+		for (int tt = 0; tt < X4_MAXP; tt++)
+			if (q < ne && tt >= tb && tt < te)
+				pcode[tt] = (pcode[tt] & 3) + 4 * q;
+	}
+
+	// ---- the row's recurrence, entry by entry, the four slots in lockstep
+	double lresA[X4_MAXL];  // finished lower blocks of the row, as element (r = m, c = k): the A-operand layout
+#pragma unroll
+	for (int q = 0; q < X4_MAXL; q++)
+		lresA[q] = 0.0;
+	int spins = 0;
+#pragma unroll
+	for (int q = 0; q < X4_MAXE; q++) {
+		const bool valid = q < ne;
+		if (__builtin_amdgcn_ballot_w64(valid) == 0ull)
+			break;
+		const bool lowerq = q < nl, diagq = valid && q == nl;
+		// wait until every operand of entry q has been published (coherent re-reads of what still is pending)
+		for (;;) {
+			bool pend = false;
+			if (q < X4_MAXL && lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0])) {
+				dvB[q < X4_MAXL ? q : 0] = x4_coherent(f + (long)dpo[q < X4_MAXL ? q : 0] * 16 + offD);
+				pend = pend || x4_pending(dvB[q < X4_MAXL ? q : 0]);
+			}
+#pragma unroll
+			for (int tt = 0; tt < X4_MAXP; tt++)
+				if ((pcode[tt] >> 2) == q && x4_pending(uvD[tt])) {
+					uvD[tt] = x4_coherent(f + (long)upo[tt] * 16 + offD);
+					pend = pend || x4_pending(uvD[tt]);
+				}
+			if (__builtin_amdgcn_ballot_w64(pend) == 0ull)
+				break;
+			spins++;
+			if (spins > X4_SPIN_LIMIT ||
+			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				if (lane == 0)
+					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		// S = A - sum L U (upper / diagonal entries, D layout) or S^T = A^T - sum U^T L^T (lower entries, A layout)
+		double acc = 0.0;
+#pragma unroll
+		for (int tt = 0; tt < X4_MAXP; tt++) {
+			const bool in = (pcode[tt] >> 2) == q;
+			if (__builtin_amdgcn_ballot_w64(in) == 0ull)
+				continue;
+			// l_ik: lower entry number pll of this row, finished above, as element (r = m, c = k)
+			const int ll = pcode[tt] & 3;
+			const double lA = ll == 0 ? lresA[0] : (ll == 1 ? lresA[1] : (ll == 2 ? lresA[2] : lresA[3]));
+			const double lv = in ? lA : 0.0, uv = in ? uvD[tt] : 0.0;
+			acc = mfma444(lowerq ? uv : lv, lowerq ? lv : uv, acc);
+		}
+		double res = aS[q] - acc;
+		if (q < X4_MAXL && __builtin_amdgcn_ballot_w64(valid && lowerq) != 0ull) {
+			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
+			const bool lw = valid && lowerq;
+			const double prod = mfma444(lw ? res : 0.0, lw ? dvB[q < X4_MAXL ? q : 0] : 0.0, 0.0);
+			if (lw)
+				res = prod;
+			const double tr = __shfl(res, 16 * m + b4 + k, 64);  // the block transposed inside its slot
+			lresA[q < X4_MAXL ? q : 0] = lw ? tr : 0.0;
+		}
+		if (__builtin_amdgcn_ballot_w64(diagq) != 0ull) {
+			const double inv = inverse_b_layout(diagq ? res : ((k == m) ? 1.0 : 0.0), k, b4, m);
+			if (diagq)
+				res = inv;
+		}
+		if (valid) {
+			double *const dst = f + (long)(jbeg + q) * 16 + offD;
+			if (lowerq)
+				*dst = res;  // read by this row (from registers) and by the triangular solves later
+			else
+				x4_publish(dst, res);
+		}
+	}
+#undef X4_SLOTLANE
+}
+
+// max over the rows of the number of position pairs of a row
+__global__ __launch_bounds__(256) void max_pairs_kernel(const Pattern pat, const int *__restrict__ posptr, int *out)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < pat.nbrows)
+		atomicMax(out, posptr[pat.browptr[i + 1]] - posptr[pat.browptr[i]]);
+}
+
 int g_factor4_enabled = -1;
 
 }  // namespace
+
+// The exact factorisation of a bs = 4 column-major matrix with stencil-like rows as one launch (see
+// sffactor4_kernel): 1 = done, 0 = does not apply, -1 = a wave gave up waiting.
+int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
+{
+	if (a.pat.bs != 4 || a.pat.rowmajor || !a.diag_inverted || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
+		return 0;
+	if (a.pat.max_row_len > X4_MAXE || ls.max_lower > X4_MAXL)
+		return 0;
+	if (ls.f4_maxpairs < 0) {
+		// once per pattern: the longest pair list of a row, and the per-level workgroup layout
+		int *d = nullptr;
+		BHIP_CHECK(tracked_malloc(&d, sizeof(int)));
+		BHIP_CHECK(hipMemsetAsync(d, 0, sizeof(int), s));
+		hipLaunchKernelGGL(max_pairs_kernel, dim3((unsigned)((a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a.pat,
+		                   a.posptr, d);
+		int h = 0;
+		BHIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+		(void)tracked_free(d);
+		ls.f4_maxpairs = h;
+		std::vector<int2> wg;
+		for (int l = 0; l < ls.nlevels; l++)
+			for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += 16)
+				wg.push_back(make_int2(q, std::min(q + 16, ls.ptr[(size_t)l + 1])));
+		ls.f4_grid = (int)wg.size();
+		BHIP_CHECK(tracked_malloc(&ls.f4_wgpos, sizeof(int2) * wg.size()));
+		BHIP_CHECK(hipMemcpyAsync(ls.f4_wgpos, wg.data(), sizeof(int2) * wg.size(), hipMemcpyHostToDevice, s));
+		BHIP_CHECK(hipStreamSynchronize(s));
+	}
+	if (ls.f4_maxpairs > X4_MAXP)
+		return 0;
+	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+	launch_factor_pending_fill(a.pat, a.out, s);
+	hipLaunchKernelGGL(sffactor4_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.meta, ls.f4_wgpos, ls.ctl);
+	BHIP_CHECK(hipGetLastError());
+	int ctl[2] = {0, 0};
+	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	return ctl[1] == 0 ? 1 : -1;
+}
 
 void set_factor4_enabled(int on)
 {

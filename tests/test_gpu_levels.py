@@ -129,21 +129,49 @@ def test_level_schedule_deep_graph_takes_the_in_order_pass(shape):
 def test_exact_factorisation_single_launch_equals_per_level(golden, case):
     """The exact factorisation as ONE launch whose rows wait for the rows they depend on (factorsf) is the same
     arithmetic in the same order as one launch per level: bit-identical factors, for every block size and layout
-    (the default uses it where a wave is one row, bs >= 5; factorsf=2 forces it everywhere)."""
+    (factorsf=3 forces the general kernel everywhere).  The default (1) and factorsf=2 may take the matrix-core
+    kernel at bs = 4 (other summation order: equal within rounding)."""
     m = matrices(golden)[case]()
     p = make_prec(m)
     res = {}
     try:
-        for k in ("0", "2", "1"):
+        for k in ("0", "3", "2", "1"):
             capi.set_tuning("factorsf=" + k)
             p.ilu0_factorize(-1)
             res[k] = p.get_iluvals()
     finally:
         capi.set_tuning("factorsf=1")
-    assert np.array_equal(res["0"], res["2"]) and np.array_equal(res["0"], res["1"])
+    assert np.array_equal(res["0"], res["3"])
+    assert rel(res["2"], res["0"]) < 1e-13 and rel(res["1"], res["0"]) < 1e-13
     assert p.level_stats()["syncfree_aborts"] == 0
     f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
     assert rel(res["2"], f) < TOL
+    p.close()
+
+
+@pytest.mark.parametrize("n,scaled", [(16, False), (11, True), (24, False)])
+def test_exact_factorisation_bs4_matrix_core_single_launch(n, scaled):
+    """bs = 4 stencil rows: the single-launch exact factorisation is the matrix-core kernel that stages a row's
+    operands before it waits (sffactor4_kernel).  It has run (a single-launch pass is counted: at bs = 4 the
+    default takes no other single-launch kernel), nobody gave up waiting, and the factor is the serial one."""
+    m = W.poisson3d(n, 4)
+    p = make_prec(m)
+    before = p.level_stats()["syncfree_passes"]
+    p.ilu0_factorize(-1, usescale=scaled)
+    st = p.level_stats()
+    impl_is_launch = st["syncfree_passes"] == before
+    capi.set_tuning("factorsf=0")
+    try:
+        g = p.get_iluvals()
+        p.ilu0_factorize(-1, usescale=scaled)
+        assert rel(g, p.get_iluvals()) < 1e-13
+    finally:
+        capi.set_tuning("factorsf=1")
+    assert st["syncfree_aborts"] == 0
+    if not impl_is_launch:   # ("level=launch" keeps one launch per level)
+        assert st["syncfree_passes"] == before + 1
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=scaled)["iluvals"]
+    assert rel(g, f) < TOL
     p.close()
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Exact (level-scheduled) ILU(0) factorisation: one launch with overlapping levels ("factorsf=1") against one
-launch per level ("factorsf=0"), on bench.py's configs.  usage: exact_factor_time.py [config | poisson:N:BS ...]"""
+"""Exact (level-scheduled) ILU(0) factorisation: one launch per level ("factorsf=0") against one launch with
+overlapping levels -- the general kernel ("factorsf=3") and, where it applies (bs = 4 stencils), the matrix-core
+kernel that prepares a row before it waits ("factorsf=2") -- on bench.py's configs.  usage: exact_factor_time.py [config | poisson:N:BS ...]"""
 import sys
 import time
 
@@ -25,7 +26,7 @@ def main():
         p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
         p.set_matrix(m)
         res = {}
-        for mode in ("0", "1"):
+        for mode in ("0", "3", "2"):
             capi.set_tuning("factorsf=" + mode)
             p.ilu0_factorize(-1)
             torch.cuda.synchronize()
@@ -38,10 +39,11 @@ def main():
         same = None
         if res["0"][1] is not None:
             import numpy as np
-            same = float(np.abs(res["0"][1] - res["1"][1]).max() / np.abs(res["0"][1]).max())
-        print("config %d (%s): %d levels; exact factorisation %.2f ms per-level launches, %.2f ms as one launch; "
-              "aborts %d; max rel difference %s" % (c, cfg["workload"], st["levels"], res["0"][0], res["1"][0],
-                                                   st["syncfree_aborts"], same), flush=True)
+            same = float(np.abs(res["0"][1] - res["2"][1]).max() / np.abs(res["0"][1]).max())
+        print("config %d (%s): %d levels; exact factorisation %.2f ms per-level launches, %.2f ms as one launch "
+              "(general kernel), %.2f ms as one launch (factorsf=2); aborts %d; max rel difference %s" % (
+                  c, cfg["workload"], st["levels"], res["0"][0], res["3"][0], res["2"][0], st["syncfree_aborts"], same),
+              flush=True)
         capi.set_tuning("factorsf=1")
         p.close()
         del m
