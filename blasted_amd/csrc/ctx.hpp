@@ -103,7 +103,7 @@ struct LevelSchedule {
 	// single-launch exact factorisation at bs = 4 (kernels_factor4.hip): longest pair list of a row (-1: not looked
 	// at yet), per-level workgroup layout
 	int f4_maxpairs = -1, f4_grid = 0;
-	int2 *f4_wgpos = nullptr;  // device, per workgroup: its range of positions in level order
+	int *f4_desc = nullptr;  // device: the rows' plans, 16 ints per row in padded level order
 };
 
 // Arrays a single-launch pass reads instead of the natural-order ones (level-ordered copies)

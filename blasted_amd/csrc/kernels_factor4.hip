@@ -168,16 +168,27 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 
 // ---- the exact factorisation as one launch, bs = 4 (round 2) ------------------------------------------------
 // The general single-launch kernel (sff_factor_kernel, kernels_factor.hip) asks for a row's operands entry by
-// entry; what bounds the exact factorisation is the chain of dependency levels (766 at 256^3), each of which then
-// costs a row's whole walk.  Here a row is prepared BEFORE it waits: its column indices, position-list pointers
-// and pairs, the diagonal positions of its lower entries' columns, and all its operand blocks -- the A blocks and
-// the (possibly still pending) blocks of other rows -- are requested up front into registers, in matrix-core
-// operand layout.  What remains between "my predecessors have published" and "I have published" is a coherent
-// re-read of what was pending, the products and the inverse on registers, and the stores.
+// entry, through four dependent index loads per row.  Here a row is prepared BEFORE it waits:
+//   - its plan -- block positions of everything it reads, the shape of its pair lists -- is one 64-byte record,
+//     written once per pattern in (padded) level order (x4_describe_kernel);
+//   - all its operand blocks -- the A blocks and the (possibly still pending) blocks of other rows -- are requested
+//     up front into registers, in matrix-core operand layout.
+// What remains between "my predecessors have published" and "I have published" is a coherent re-read of what was
+// pending, the products and the inverse on registers, and the stores.
 // One wave = four block slots = four rows of ONE level (workgroups are laid out per level, so that the rows of a
 // wave never depend on each other and the wave can walk its entries in lockstep, q = 0, 1, ... with compile-time
 // register indices).  For stencil-like rows only: at most X4_MAXE entries, X4_MAXL of them lower, X4_MAXP position
 // pairs per row; other patterns take the general kernel.
+// Measured (MI355X, ms per exact factorisation, one launch per level -> general single launch -> this):
+//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 11.5;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.6.
+// How it got there, at 256^3: first form (indices through the matrix's own arrays, level of a workgroup by binary
+// search) 17.8; per-workgroup table 14.6; row plans 13.3; shape in scalar registers where the four rows agree
+// 13.0; upper blocks without pairs stored by the fill pass instead 11.5.  With nobody waiting (wrong factor,
+// experiment) the same launches take 10.4: the dependency chain costs about a millisecond, the rest is the rate at
+// which four waves per SIMD (110 registers, 80 of them operand blocks) turn rows over.  Tried and dropped: a
+// resident grid whose waves walk the units with the next plan requested ahead (15.5 against 14.1 for the form it
+// was tried on); five waves per SIMD by register bound (spills: 31 ms); re-reading the pending operands of LATER
+// entries while waiting for the current one (no change).
 constexpr int X4_MAXE = 8, X4_MAXL = 4, X4_MAXP = 8;
 constexpr unsigned long long X4_PENDING = 0xFFF8DEADBEEF0001ull;  // = SFF_PENDING (kernels_factor.hip)
 constexpr int X4_SPIN_LIMIT = 1 << 22;
@@ -199,76 +210,150 @@ __device__ __forceinline__ void x4_publish(double *p, const double v)
 	                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, const int4 *__restrict__ meta,
-                                                        const int2 *__restrict__ wgpos, int *ctl)
+// The plan of a row (16 ints, one per lane of its block slot), in padded level order (every level starts a new
+// workgroup of 16 rows): what the kernel below would otherwise collect through four dependent index loads (level
+// order -> row pointers -> column indices / position-list pointers -> pairs / diagonal positions).
+//   0 first block position of the row   1 block-row   2..9 position of the upper block of pair tt
+//   10..13 position of the diagonal block of the column of lower entry q
+//   14: ne | nl << 4 | np << 8 | code(0..3) << (12 + 5 tt)     15: code(4..7) << 5 (tt - 4)
+//   code(tt) = (entry the pair belongs to) | (lower entry of this row it multiplies) << 3
+constexpr int X4_DESC = 16;
+
+__global__ __launch_bounds__(256) void x4_describe_kernel(const FactorArgs a, const int4 *__restrict__ meta,
+                                                          const int2 *__restrict__ wgpos, const int nwg,
+                                                          int *__restrict__ desc)
 {
-	const int tid = threadIdx.x;
-	const int lane = tid & 63, wave = tid >> 6;
-	const int k = lane >> 4, b = (lane >> 2) & 3, m = lane & 3;
-	const int b4 = 4 * b;
+	const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+	const long slot = gid >> 4;  // padded position
+	const int t = (int)(gid & 15);
+	if (slot >= (long)nwg * 16)
+		return;
+	const int2 wp = wgpos[slot >> 4];
+	const int pos = wp.x + (int)(slot & 15);
+	int w = 0;
+	if (pos < wp.y) {
+		const int4 md = meta[pos];
+		const int jbeg = md.y, ne = md.w - md.y, nl = md.z - md.y;
+		const int pbeg = a.posptr[jbeg], np = a.posptr[md.w] - pbeg;
+		if (t == 0)
+			w = jbeg;
+		else if (t == 1)
+			w = md.x;
+		else if (t < 10)
+			w = (t - 2 < np) ? a.upperp[pbeg + t - 2] : 0;
+		else if (t < 14)
+			w = (t - 10 < nl) ? a.pat.diagind[a.pat.bcolind[jbeg + t - 10]] : 0;
+		else {
+			unsigned bits = (t == 14) ? (unsigned)(ne | (nl << 4) | (np << 8)) : 0u;
+			const int tt0 = (t == 14) ? 0 : 4, sh0 = (t == 14) ? 12 : 0;
+			for (int x = 0; x < 4; x++) {
+				const int tt = tt0 + x;
+				if (tt < np) {
+					int q = 0;
+					while (q + 1 < ne && a.posptr[jbeg + q + 1] - pbeg <= tt)
+						q++;
+					const int ll = a.lowerp[pbeg + tt] - jbeg;
+					bits |= (unsigned)(q | (ll << 3)) << (sh0 + 5 * x);
+				}
+			}
+			w = (int)bits;
+		}
+	}
+	desc[gid] = w;
+}
+
+// Before the launch: the diagonal + upper part of every row <- the fill pattern, except upper blocks WITHOUT
+// position pairs: their factor value is the (scaled) matrix block, which is stored here, in natural order at
+// streaming rate, instead of going through the dependency kernel (3 of a 7-point row's 7 blocks).
+__global__ __launch_bounds__(256) void x4_fill_kernel(const FactorArgs a)
+{
+	const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+	const int t = threadIdx.x & 15, base = threadIdx.x & 48;  // 16 lanes per row (rows of at most X4_MAXE blocks)
+	const bool rowok = row < a.pat.nbrows;
+	const int dg = rowok ? a.pat.diagind[row] : 0;
+	const int nu = rowok ? a.pat.browptr[row + 1] - dg : 0;  // diagonal + upper blocks
+	const int pp = (t <= nu && rowok) ? a.posptr[dg + t] : 0;
+	const int colr = (a.scale && t < nu) ? a.pat.bcolind[dg + t] : 0;
+	bool copy[X4_MAXE];
+	double v[X4_MAXE];
+#pragma unroll
+	for (int x = 0; x < X4_MAXE; x++) {
+		const int p0 = __shfl(pp, base + x, 64), p1 = __shfl(pp, base + x + 1, 64);
+		copy[x] = x > 0 && x < nu && p0 == p1;
+		v[x] = copy[x] ? a.avals[(long)(dg + x) * 16 + t] : 0.0;
+	}
+	unsigned long long *const fq = reinterpret_cast<unsigned long long *>(a.out);
+#pragma unroll
+	for (int x = 0; x < X4_MAXE; x++) {
+		const int cx = __shfl(colr, base + x, 64);
+		if (copy[x]) {
+			if (a.scale)
+				v[x] *= a.scale[(long)row * 4 + (t & 3)] * a.scale[(long)cx * 4 + (t >> 2)];
+			a.out[(long)(dg + x) * 16 + t] = v[x];
+		} else if (x < nu)
+			fq[(long)(dg + x) * 16 + t] = X4_PENDING;
+	}
+}
+
+// The four rows of a wave.  UNI: all of them (but for empty slots at the end of a level) have the same shape --
+// the same plan words 14 and 15, which is what the interior rows of a stencil look like -- and the shape arrives in
+// scalar registers: which entry is lower, which pair belongs to which entry, where a row ends are then scalar
+// branches instead of 64-bit lane masks and selects (the instruction issue of exactly that bookkeeping is what
+// bounded the first form of this kernel: 11 ms at 256^3 with nobody waiting).  Returns false if the wave gave up.
+template <bool UNI>
+__device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const unsigned w14, const unsigned w15,
+                                        const bool ok, const int lane, int *ctl)
+{
+	const int k = lane >> 4, b4 = ((lane >> 2) & 3) * 4, m = lane & 3;
 	const int t = 4 * k + m;     // index of this lane inside its block slot
 	const int offA = k * 4 + m;  // element (r = m, c = k)
 	const int offD = m * 4 + k;  // element (r = k, c = m)
 	double *const f = a.out;
-
-	// this workgroup's rows: positions [wp.x, wp.y) of the level order, all of one level
-	const int2 wp = wgpos[blockIdx.x];
-	const int pos = wp.x + wave * 4 + b;
-	const bool rowok = pos < wp.y;
-	const int4 md = rowok ? meta[pos] : make_int4(0, 0, 0, 0);  // {row, browptr, diagind, browptr of the next row}
-	const int irow = md.x, jbeg = md.y;
-	const int ne = rowok ? md.w - md.y : 0, nl = rowok ? md.z - md.y : 0;
 #define X4_SLOTLANE(Q) (16 * ((Q) >> 2) + b4 + ((Q) & 3))
-
-	// ---- indices of the row, one entry / pair per lane of the slot
-	const int colr = (t < ne) ? a.pat.bcolind[jbeg + t] : 0;
-	const int ppr = (rowok && t <= ne) ? a.posptr[jbeg + t] : 0;
-	const int pbeg = __shfl(ppr, X4_SLOTLANE(0), 64);
-	const int np = __shfl(ppr, X4_SLOTLANE(ne), 64) - pbeg;
-	const int lpr = (t < np) ? a.lowerp[pbeg + t] : 0;
-	const int upr = (t < np) ? a.upperp[pbeg + t] : 0;
-	const int dposr = (t < nl) ? a.pat.diagind[colr] : 0;
+	const int jbeg = __shfl(dw, X4_SLOTLANE(0), 64);
+	const int ne = (int)(w14 & 15u), nl = (int)((w14 >> 4) & 15u), np = (int)((w14 >> 8) & 15u);
+	// pair tt: the entry it belongs to (8 = none), the lower entry of this row it multiplies
+#define X4_CODE(TT) ((TT) < 4 ? (w14 >> (12 + 5 * (TT))) : (w15 >> (5 * ((TT)-4))))
+#define X4_PQ(TT) ((TT) < np ? (int)(X4_CODE(TT) & 7u) : 8)
+#define X4_PLL(TT) ((int)((X4_CODE(TT) >> 3) & 3u))
+#define X4_ANY(C) (UNI ? (C) : (__builtin_amdgcn_ballot_w64(C) != 0ull))
+	// entries with position pairs; an upper entry without any has been stored by x4_fill_kernel already
+	unsigned pmask = 0u;
+#pragma unroll
+	for (int tt = 0; tt < X4_MAXP; tt++)
+		pmask |= (tt < np) ? (1u << (X4_CODE(tt) & 7u)) : 0u;
+#define X4_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
 
 	// ---- operands, in operand layout; blocks of other rows may still show the fill pattern
+	// (lane exchanges are kept out of divergent code: a lane that is switched off hands out nothing)
 	double aS[X4_MAXE], uvD[X4_MAXP], dvB[X4_MAXL];
 #pragma unroll
-	for (int q = 0; q < X4_MAXE; q++) {
-		const bool lowerq = q < nl;
-		aS[q] = (q < ne) ? a.avals[(long)(jbeg + q) * 16 + (lowerq ? offA : offD)] : 0.0;
-		if (a.scale && q < ne) {
-			const int cq = __shfl(colr, X4_SLOTLANE(q), 64);
-			const int r = lowerq ? m : k, c = lowerq ? k : m;  // (r,c) of this lane's entry: D layout (k,m), transposed (m,k)
-			aS[q] *= a.scale[(long)irow * 4 + r] * a.scale[(long)cq * 4 + c];
-		}
-	}
-	// (lane exchanges are kept out of divergent code and out of the waiting loops: a lane that is switched off hands
-	// out nothing, and an exchange costs about as much as a cache hit)
-	int upo[X4_MAXP], dpo[X4_MAXL];
+	for (int q = 0; q < X4_MAXE; q++)
+		aS[q] = (X4_TODO(q) && ok) ? a.avals[(long)(jbeg + q) * 16 + (q < nl ? offA : offD)] : 0.0;
 #pragma unroll
 	for (int tt = 0; tt < X4_MAXP; tt++) {
-		upo[tt] = __shfl(upr, X4_SLOTLANE(tt), 64);
-		uvD[tt] = (tt < np) ? f[(long)upo[tt] * 16 + offD] : 0.0;
+		const int up = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
+		uvD[tt] = (tt < np && ok) ? f[(long)up * 16 + offD] : 0.0;
 	}
 #pragma unroll
 	for (int q = 0; q < X4_MAXL; q++) {
-		dpo[q] = __shfl(dposr, X4_SLOTLANE(q), 64);
-		dvB[q] = (q < nl) ? f[(long)dpo[q] * 16 + offD] : 0.0;
+		const int dp = __shfl(dw, X4_SLOTLANE(10 + q), 64);
+		dvB[q] = (q < nl && ok) ? f[(long)dp * 16 + offD] : 0.0;
 	}
-	// pair tt: 4 * (the entry it belongs to; 8 = none) + the lower entry of this row it multiplies
-	int pcode[X4_MAXP];
+	if (a.scale) {
+		const int irow = __shfl(dw, X4_SLOTLANE(1), 64);
+		const int colr = (t < ne && ok) ? a.pat.bcolind[jbeg + t] : 0;
 #pragma unroll
-	for (int tt = 0; tt < X4_MAXP; tt++)
-		pcode[tt] = 32 + ((__shfl(lpr, X4_SLOTLANE(tt), 64) - jbeg) & 3);
-#pragma unroll
-	for (int q = 0; q < X4_MAXE; q++) {
-		const int tb = __shfl(ppr, X4_SLOTLANE(q), 64) - pbeg, te = __shfl(ppr, X4_SLOTLANE(q + 1), 64) - pbeg;
-#pragma unroll
-		for (int tt = 0; tt < X4_MAXP; tt++)
-			if (q < ne && tt >= tb && tt < te)
-				pcode[tt] = (pcode[tt] & 3) + 4 * q;
+		for (int q = 0; q < X4_MAXE; q++) {
+			const int cq = __shfl(colr, X4_SLOTLANE(q), 64);
+			// (r,c) of this lane's element: D layout (k,m), transposed (m,k)
+			const int r = q < nl ? m : k, c = q < nl ? k : m;
+			if (X4_TODO(q) && ok)
+				aS[q] *= a.scale[(long)irow * 4 + r] * a.scale[(long)cq * 4 + c];
+		}
 	}
 
-	// ---- the row's recurrence, entry by entry, the four slots in lockstep
+	// ---- the rows' recurrence, entry by entry, the four slots in lockstep
 	double lresA[X4_MAXL];  // finished lower blocks of the row, as element (r = m, c = k): the A-operand layout
 #pragma unroll
 	for (int q = 0; q < X4_MAXL; q++)
@@ -276,31 +361,44 @@ __global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, cons
 	int spins = 0;
 #pragma unroll
 	for (int q = 0; q < X4_MAXE; q++) {
-		const bool valid = q < ne;
-		if (__builtin_amdgcn_ballot_w64(valid) == 0ull)
+		if (!X4_ANY(q < ne))
 			break;
+		const bool valid = X4_TODO(q);
+		if (!X4_ANY(valid))
+			continue;
 		const bool lowerq = q < nl, diagq = valid && q == nl;
-		// wait until every operand of entry q has been published (coherent re-reads of what still is pending)
+		// wait until every operand of entry q has been published
 		for (;;) {
 			bool pend = false;
-			if (q < X4_MAXL && lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0])) {
-				dvB[q < X4_MAXL ? q : 0] = x4_coherent(f + (long)dpo[q < X4_MAXL ? q : 0] * 16 + offD);
-				pend = pend || x4_pending(dvB[q < X4_MAXL ? q : 0]);
-			}
+			if (q < X4_MAXL)
+				pend = lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0]);
 #pragma unroll
 			for (int tt = 0; tt < X4_MAXP; tt++)
-				if ((pcode[tt] >> 2) == q && x4_pending(uvD[tt])) {
-					uvD[tt] = x4_coherent(f + (long)upo[tt] * 16 + offD);
-					pend = pend || x4_pending(uvD[tt]);
-				}
+				if (UNI ? X4_PQ(tt) == q : true)
+					pend = pend || (X4_PQ(tt) == q && x4_pending(uvD[tt]));
 			if (__builtin_amdgcn_ballot_w64(pend) == 0ull)
 				break;
+			// the whole wave re-reads, coherently, what still shows the fill pattern (the positions come out of the
+			// plan again: they are not worth registers)
+			if (q < X4_MAXL) {
+				const int dp = __shfl(dw, X4_SLOTLANE(10 + (q < X4_MAXL ? q : 0)), 64);
+				if (lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0]))
+					dvB[q < X4_MAXL ? q : 0] = x4_coherent(f + (long)dp * 16 + offD);
+			}
+#pragma unroll
+			for (int tt = 0; tt < X4_MAXP; tt++) {
+				if (!X4_ANY(X4_PQ(tt) == q))
+					continue;
+				const int up = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
+				if (X4_PQ(tt) == q && x4_pending(uvD[tt]))
+					uvD[tt] = x4_coherent(f + (long)up * 16 + offD);
+			}
 			spins++;
 			if (spins > X4_SPIN_LIMIT ||
 			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
 				if (lane == 0)
 					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				return;
+				return false;
 			}
 			__builtin_amdgcn_s_sleep(1);
 		}
@@ -308,31 +406,31 @@ __global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, cons
 		double acc = 0.0;
 #pragma unroll
 		for (int tt = 0; tt < X4_MAXP; tt++) {
-			const bool in = (pcode[tt] >> 2) == q;
-			if (__builtin_amdgcn_ballot_w64(in) == 0ull)
+			const bool in = X4_PQ(tt) == q;
+			if (!X4_ANY(in))
 				continue;
 			// l_ik: lower entry number pll of this row, finished above, as element (r = m, c = k)
-			const int ll = pcode[tt] & 3;
+			const int ll = X4_PLL(tt);
 			const double lA = ll == 0 ? lresA[0] : (ll == 1 ? lresA[1] : (ll == 2 ? lresA[2] : lresA[3]));
-			const double lv = in ? lA : 0.0, uv = in ? uvD[tt] : 0.0;
+			const double lv = (UNI || in) ? lA : 0.0, uv = (UNI || in) ? uvD[tt] : 0.0;
 			acc = mfma444(lowerq ? uv : lv, lowerq ? lv : uv, acc);
 		}
 		double res = aS[q] - acc;
-		if (q < X4_MAXL && __builtin_amdgcn_ballot_w64(valid && lowerq) != 0ull) {
+		if (q < X4_MAXL && X4_ANY(valid && lowerq)) {
 			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
 			const bool lw = valid && lowerq;
-			const double prod = mfma444(lw ? res : 0.0, lw ? dvB[q < X4_MAXL ? q : 0] : 0.0, 0.0);
+			const double prod = mfma444((UNI || lw) ? res : 0.0, (UNI || lw) ? dvB[q < X4_MAXL ? q : 0] : 0.0, 0.0);
 			if (lw)
 				res = prod;
 			const double tr = __shfl(res, 16 * m + b4 + k, 64);  // the block transposed inside its slot
 			lresA[q < X4_MAXL ? q : 0] = lw ? tr : 0.0;
 		}
-		if (__builtin_amdgcn_ballot_w64(diagq) != 0ull) {
-			const double inv = inverse_b_layout(diagq ? res : ((k == m) ? 1.0 : 0.0), k, b4, m);
+		if (q <= X4_MAXL && X4_ANY(diagq)) {
+			const double inv = inverse_b_layout((diagq && ok) ? res : ((k == m) ? 1.0 : 0.0), k, b4, m);
 			if (diagq)
 				res = inv;
 		}
-		if (valid) {
+		if (valid && ok) {
 			double *const dst = f + (long)(jbeg + q) * 16 + offD;
 			if (lowerq)
 				*dst = res;  // read by this row (from registers) and by the triangular solves later
@@ -340,7 +438,35 @@ __global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, cons
 				x4_publish(dst, res);
 		}
 	}
+	return true;
 #undef X4_SLOTLANE
+#undef X4_CODE
+#undef X4_PQ
+#undef X4_PLL
+#undef X4_ANY
+#undef X4_TODO
+}
+
+// One wave = one unit of four rows of one level; workgroups in level order (that the row with the lowest number
+// among the unfinished ones can always move rests on workgroups being started in the order of their numbers, as
+// for the other single-launch kernels).
+__global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
+{
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int b = (lane >> 2) & 3, t = 4 * (lane >> 4) + (lane & 3);
+	// the rows' plans: one word per lane of the slot (a wave reads 256 consecutive bytes)
+	const int dw = desc[((long)blockIdx.x * 16 + (tid >> 6) * 4 + b) * X4_DESC + t];
+	const unsigned w14 = (unsigned)__shfl(dw, 48 + 4 * b + 2, 64), w15 = (unsigned)__shfl(dw, 48 + 4 * b + 3, 64);
+	const unsigned s14 = (unsigned)__builtin_amdgcn_readfirstlane((int)w14);
+	const unsigned s15 = (unsigned)__builtin_amdgcn_readfirstlane((int)w15);
+	if (s14 == 0u)
+		return;  // (slots fill up in order: an empty first slot is an empty wave)
+	const bool same = (w14 == s14 && w15 == s15) || w14 == 0u;
+	if (__builtin_amdgcn_ballot_w64(!same) == 0ull)
+		(void)x4_rows<true>(a, dw, s14, s15, w14 != 0u, lane, ctl);
+	else
+		(void)x4_rows<false>(a, dw, w14, w15, w14 != 0u, lane, ctl);
 }
 
 // max over the rows of the number of position pairs of a row
@@ -375,20 +501,29 @@ int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 		BHIP_CHECK(hipStreamSynchronize(s));
 		(void)tracked_free(d);
 		ls.f4_maxpairs = h;
-		std::vector<int2> wg;
-		for (int l = 0; l < ls.nlevels; l++)
-			for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += 16)
-				wg.push_back(make_int2(q, std::min(q + 16, ls.ptr[(size_t)l + 1])));
-		ls.f4_grid = (int)wg.size();
-		BHIP_CHECK(tracked_malloc(&ls.f4_wgpos, sizeof(int2) * wg.size()));
-		BHIP_CHECK(hipMemcpyAsync(ls.f4_wgpos, wg.data(), sizeof(int2) * wg.size(), hipMemcpyHostToDevice, s));
-		BHIP_CHECK(hipStreamSynchronize(s));
+		if (ls.f4_maxpairs <= X4_MAXP) {
+			std::vector<int2> wg;
+			for (int l = 0; l < ls.nlevels; l++)
+				for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += 16)
+					wg.push_back(make_int2(q, std::min(q + 16, ls.ptr[(size_t)l + 1])));
+			ls.f4_grid = (int)wg.size();
+			int2 *wgpos = nullptr;
+			BHIP_CHECK(tracked_malloc(&wgpos, sizeof(int2) * wg.size()));
+			BHIP_CHECK(hipMemcpyAsync(wgpos, wg.data(), sizeof(int2) * wg.size(), hipMemcpyHostToDevice, s));
+			const long nd = (long)ls.f4_grid * 16 * X4_DESC;
+			BHIP_CHECK(tracked_malloc(&ls.f4_desc, sizeof(int) * (size_t)nd));
+			hipLaunchKernelGGL(x4_describe_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a, ls.meta, wgpos,
+			                   ls.f4_grid, ls.f4_desc);
+			BHIP_CHECK(hipGetLastError());
+			BHIP_CHECK(hipStreamSynchronize(s));
+			(void)tracked_free(wgpos);
+		}
 	}
 	if (ls.f4_maxpairs > X4_MAXP)
 		return 0;
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
-	launch_factor_pending_fill(a.pat, a.out, s);
-	hipLaunchKernelGGL(sffactor4_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.meta, ls.f4_wgpos, ls.ctl);
+	hipLaunchKernelGGL(x4_fill_kernel, dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(sffactor4_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc, ls.ctl);
 	BHIP_CHECK(hipGetLastError());
 	int ctl[2] = {0, 0};
 	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));

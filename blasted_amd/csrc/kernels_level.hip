@@ -662,8 +662,8 @@ void free_level_schedule(LevelSchedule &ls)
 		(void)tracked_free(ls.meta);
 	if (ls.ctl)
 		(void)tracked_free(ls.ctl);
-	if (ls.f4_wgpos)
-		(void)tracked_free(ls.f4_wgpos);
+	if (ls.f4_desc)
+		(void)tracked_free(ls.f4_desc);
 	for (void *q : {(void *)ls.lptr, (void *)ls.uptr, (void *)ls.lcol, (void *)ls.ucol, (void *)ls.lmeta,
 	                (void *)ls.umeta, (void *)ls.lhead, (void *)ls.uhead, (void *)ls.posof, (void *)ls.lcolp,
 	                (void *)ls.ucolp, (void *)ls.lheadp, (void *)ls.uheadp})
