@@ -225,7 +225,12 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * ASYNC-mode SGS application as one exact pass (the reference's semantics) or as asynchronous sweeps.
  * "levelperm=0": the exact ILU solves keep natural-order vectors instead of a level-ordered iterate.
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
- * lets a wave of that kernel prefetch several row steps instead of one. */
+ * lets a wave of that kernel prefetch several row steps instead of one.
+ * "factorsf=0|1|2|3": the exact factorisation as one launch per dependency level (0), as one dependency-polling
+ * launch where that is faster (1, default: bs >= 5, and column-major bs = 4 with stencil-like rows through the
+ * matrix-core kernel), always as one launch (2), or always as one launch of the general kernel, whose factor is
+ * bit-identical to the per-level one (3).  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
+ * measurement switches described where they are read (capi.hip). */
 int blasted_hip_set_tuning(const char *spec);
 
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */

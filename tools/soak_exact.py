@@ -2,6 +2,8 @@
 """Soak test of the single-launch (dependency-polling) exact passes: many repetitions at several sizes
 and block sizes; every repetition must reproduce the first result BIT FOR BIT (the exact pass is
 deterministic: each row is one fixed expression of final inputs) and no pass may have given up waiting.
+The single-launch exact FACTORISATIONS (kernels_factor.hip / kernels_factor4.hip) are soaked the same way, with
+the exact apply of the fresh factor as the checksum.
 usage: soak_exact.py [reps]"""
 import sys
 import time
@@ -42,6 +44,21 @@ def main():
         print("n=%d bs=%d rows=%d: %d exact applies in %.1f s, mismatches %d, %s" % (
             n, bs, m["nbrows"], k, time.perf_counter() - t0, bad, st), flush=True)
         assert bad == 0 and st["syncfree_aborts"] == 0
+        # exact factorisations: the exact apply of each fresh factor must be the same bits
+        p.ilu0_factorize(-1)
+        f0 = p.ilu0_apply(r, 1, mode=capi.LEVEL).clone()
+        kf = max(1, k // 4)
+        t0 = time.perf_counter()
+        for i in range(kf):
+            p.ilu0_factorize(-1)
+            p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z)
+            if not torch.equal(z, f0):
+                bad += 1
+        torch.cuda.synchronize()
+        st2 = p.level_stats()
+        print("n=%d bs=%d: %d exact factorisations in %.1f s, mismatches %d, single-launch passes %d, %s" % (
+            n, bs, kf, time.perf_counter() - t0, bad, st2["syncfree_passes"] - st["syncfree_passes"], st2), flush=True)
+        assert bad == 0 and st2["syncfree_aborts"] == 0
         p.close()
         del m, r, z, z0, s0
         torch.cuda.empty_cache()
