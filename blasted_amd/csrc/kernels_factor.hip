@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void sff_factor_kernel(const FactorArgs a, con
 }
 
 // tuning "factorsf=0|1|2|3": one launch per level | one launch where it pays | always one launch | always one
-// launch of the general kernel (no matrix-core kernel at bs = 4: bit-identical to the per-level form)
+// launch of the general kernel (no matrix-core kernel at bs = 4); the factor is the same bits in every form
 static int g_factor_syncfree = 1;
 void set_factor_syncfree(int on)
 {

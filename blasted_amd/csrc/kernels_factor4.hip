@@ -402,8 +402,10 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 			}
 			__builtin_amdgcn_s_sleep(1);
 		}
-		// S = A - sum L U (upper / diagonal entries, D layout) or S^T = A^T - sum U^T L^T (lower entries, A layout)
-		double acc = 0.0;
+		// S = A - sum L U (upper / diagonal entries, D layout) or S^T = A^T - sum U^T L^T (lower entries, A layout).
+		// Pair by pair, each product summed from zero and then subtracted: the order of the general kernels
+		// (s -= group_gemm(l, u), kernels_factor.hip), so that the factor is the same bits.
+		double res = aS[q];
 #pragma unroll
 		for (int tt = 0; tt < X4_MAXP; tt++) {
 			const bool in = X4_PQ(tt) == q;
@@ -413,9 +415,8 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 			const int ll = X4_PLL(tt);
 			const double lA = ll == 0 ? lresA[0] : (ll == 1 ? lresA[1] : (ll == 2 ? lresA[2] : lresA[3]));
 			const double lv = (UNI || in) ? lA : 0.0, uv = (UNI || in) ? uvD[tt] : 0.0;
-			acc = mfma444(lowerq ? uv : lv, lowerq ? lv : uv, acc);
+			res -= mfma444(lowerq ? uv : lv, lowerq ? lv : uv, 0.0);
 		}
-		double res = aS[q] - acc;
 		if (q < X4_MAXL && X4_ANY(valid && lowerq)) {
 			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
 			const bool lw = valid && lowerq;
