@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void x4_fill_kernel(const FactorArgs a)
 		const int cx = __shfl(colr, base + x, 64);
 		if (copy[x]) {
 			if (a.scale)
-				v[x] *= a.scale[(long)row * 4 + (t & 3)] * a.scale[(long)cx * 4 + (t >> 2)];
+				v[x] *= a.scale[(long)row * 4 + (a.pat.rowmajor ? t >> 2 : t & 3)] *
+				        a.scale[(long)cx * 4 + (a.pat.rowmajor ? t & 3 : t >> 2)];
 			a.out[(long)(dg + x) * 16 + t] = v[x];
 		} else if (x < nu)
 			fq[(long)(dg + x) * 16 + t] = X4_PENDING;
@@ -306,8 +307,8 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 {
 	const int k = lane >> 4, b4 = ((lane >> 2) & 3) * 4, m = lane & 3;
 	const int t = 4 * k + m;     // index of this lane inside its block slot
-	const int offA = k * 4 + m;  // element (r = m, c = k)
-	const int offD = m * 4 + k;  // element (r = k, c = m)
+	const int offA = a.pat.rowmajor ? m * 4 + k : k * 4 + m;  // element (r = m, c = k)
+	const int offD = a.pat.rowmajor ? k * 4 + m : m * 4 + k;  // element (r = k, c = m)
 	double *const f = a.out;
 #define X4_SLOTLANE(Q) (16 * ((Q) >> 2) + b4 + ((Q) & 3))
 	const int jbeg = __shfl(dw, X4_SLOTLANE(0), 64);
@@ -482,11 +483,11 @@ int g_factor4_enabled = -1;
 
 }  // namespace
 
-// The exact factorisation of a bs = 4 column-major matrix with stencil-like rows as one launch (see
+// The exact factorisation of a bs = 4 matrix (either block layout) with stencil-like rows as one launch (see
 // sffactor4_kernel): 1 = done, 0 = does not apply, -1 = a wave gave up waiting.
 int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
 {
-	if (a.pat.bs != 4 || a.pat.rowmajor || !a.diag_inverted || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
+	if (a.pat.bs != 4 || !a.diag_inverted || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
 		return 0;
 	if (a.pat.max_row_len > X4_MAXE || ls.max_lower > X4_MAXL)
 		return 0;

@@ -227,7 +227,7 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
  * lets a wave of that kernel prefetch several row steps instead of one.
  * "factorsf=0|1|2|3": the exact factorisation as one launch per dependency level (0), as one dependency-polling
- * launch where that is faster (1, default: bs >= 5, and column-major bs = 4 with stencil-like rows through the
+ * launch where that is faster (1, default: bs >= 5, and bs = 4 with stencil-like rows through the
  * matrix-core kernel), always as one launch (2), or always as one launch of the general kernel (3); the factor
  * is the same bits in every form.  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
  * measurement switches described where they are read (capi.hip). */

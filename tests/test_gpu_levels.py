@@ -149,12 +149,13 @@ def test_exact_factorisation_single_launch_equals_per_level(golden, case):
     p.close()
 
 
-@pytest.mark.parametrize("n,scaled", [(16, False), (11, True), (24, False)])
-def test_exact_factorisation_bs4_matrix_core_single_launch(n, scaled):
+@pytest.mark.parametrize("n,scaled,rowmajor", [(16, False, False), (11, True, False), (24, False, False),
+                                               (12, False, True), (9, True, True)])
+def test_exact_factorisation_bs4_matrix_core_single_launch(n, scaled, rowmajor):
     """bs = 4 stencil rows: the single-launch exact factorisation is the matrix-core kernel that stages a row's
     operands before it waits (sffactor4_kernel).  It has run (a single-launch pass is counted: at bs = 4 the
     default takes no other single-launch kernel), nobody gave up waiting, and the factor is the serial one."""
-    m = W.poisson3d(n, 4)
+    m = W.poisson3d(n, 4, rowmajor=rowmajor)
     p = make_prec(m)
     before = p.level_stats()["syncfree_passes"]
     p.ilu0_factorize(-1, usescale=scaled)
