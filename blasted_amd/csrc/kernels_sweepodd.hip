@@ -266,7 +266,9 @@ void launch5(const SweepArgs &a, hipStream_t s)
 {
 	constexpr int RCHUNK = 128;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
-	constexpr int OCCT = (PART == PART_LOWER || PART == PART_UPPER) ? 6 : 1;
+	// (whole-row parts: eight straight-line passes; five waves is what they had before the grouped remainder
+	// passes cost them 21 registers -- SpMV at bs=5 0.69 -> 0.78 ms without the bound)
+	constexpr int OCCT = (PART == PART_LOWER || PART == PART_UPPER) ? 6 : ((PART == PART_ALL || PART == PART_OFFDIAG) ? 5 : 1);
 #define BHIP_ODD(B)                                                                                                    \
 	if (g_sweepodd_nt)                                                                                                 \
 		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, true, 1>), dim3(grid), dim3(256), 0, s, a);    \
