@@ -504,6 +504,10 @@ static int g_xcd_shift = 4;
 // whole-row exact kernel
 static int g_relax_split = 1;
 
+// tuning ("factorskip=0|1"): in-place factorisation sweeps after the first leave upper blocks without position
+// pairs alone (their value, the scaled matrix block, does not change from sweep to sweep)
+static int g_factor_skip_fixed = 1;
+
 // tuning ("sgsfwd=exact|async"): the forward half of an ASYNC-mode SGS application as one exact in-order pass (the
 // reference's semantics, default) or as napplysweeps asynchronous sweeps
 static int g_sgs_exact_fwd = 1;
@@ -870,6 +874,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.rows = nullptr;
 		fa.nrows = 0;
 		fa.diag_inverted = 0;
+		fa.skip_fixed = 0;
 		fa.dinv_scratch = nullptr;
 		if (pat.bs >= 5)
 			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * pat.bs * pat.bs);
@@ -921,6 +926,8 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 				}
 				fa.in = cur;
 				fa.out = out;
+				// (from the first sweep on after INIT_F_ORIGINAL: the initialisation pass has stored exactly those values)
+				fa.skip_fixed = ((s > 0 || fact_init == BLASTED_HIP_INIT_F_ORIGINAL) && out == cur && g_factor_skip_fixed) ? 1 : 0;
 				launch_factor_sweep(fa, p->stream);
 				ph.launches++;
 				cur = out;
@@ -1769,6 +1776,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)
 			g_sgs_exact_fwd = std::strcmp(spec + 7, "async") != 0;
+		else if (spec && std::strncmp(spec, "factorskip=", 11) == 0)
+			g_factor_skip_fixed = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "factorsf=", 9) == 0)
 			set_factor_syncfree(spec[9] - '0');
 		else if (spec && std::strncmp(spec, "factor1=", 8) == 0)

@@ -129,6 +129,8 @@ struct FactorArgs {
 	int nrows;              // length of `rows`
 	int diag_inverted;      // exact factorisation, bs > 1: diagonal blocks are stored inverted as soon as they are
 	                        // final, and lower blocks multiply with the stored inverse (general kernel only)
+	int skip_fixed;         // in-place sweeps after the first: an upper block without position pairs is the (scaled)
+	                        // matrix block, which the sweep before has stored -- neither read nor written again
 };
 
 // kernels_sweep.hip

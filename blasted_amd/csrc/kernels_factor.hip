@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 
 	for (int jpos = jbeg; jpos < jend; jpos++) {
 		const int col = a.pat.bcolind[jpos];
+		if (!RESID && a.skip_fixed && col > irow && a.posptr[jpos + 1] == a.posptr[jpos])
+			continue;  // an upper entry without pairs: the sweep before has stored its value, a_ij
 		double s = active ? a.avals[(long)jpos * BS2 + e] : 0.0;
 		if (a.scale && active) {
 			if (BS == 1) {

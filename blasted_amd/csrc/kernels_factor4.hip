@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 		const int len = rowok ? s_rp[ls + 1] - jbeg : 0;
 
 		for (int p = 0; __any(p < len); p++) {
-			const bool valid = p < len;
+			const bool inrow = p < len;
 			const int jpos = jbeg + p;
 			const int bidx = jpos - jlo;
 			int col = 0, kb = 0, ke = 0;
-			if (valid) {
+			if (inrow) {
 				if (bidx < F4_CAPB) {
 					col = s_col[bidx];
 					kb = s_pp[bidx];
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 					ke = a.posptr[jpos + 1];
 				}
 			}
+			// (sweeps after the first, in place: an upper block without pairs already holds its value, a_ij)
+			const bool valid = inrow && !(a.skip_fixed && col > irow && ke == kb);
 			const bool lower = valid && irow > col;
 			// lower blocks work on S^T (A-operand layout), the others on S (D layout)
 			const int offS = lower ? offA : offD;

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 			kb = __builtin_amdgcn_readfirstlane(kb);
 			ke = __builtin_amdgcn_readfirstlane(ke);
 			const bool lower = irow > col;
+			if (a.skip_fixed && col > irow && ke == kb)
+				continue;  // an upper block without pairs: the sweep before has stored its value, a_ij
 
 			double sval = a.avals[(long)jpos * 64 + offD];
 			double d0 = 0.0, d1 = 0.0;

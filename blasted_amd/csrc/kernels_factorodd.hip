@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 
 	for (int jpos = jbeg; jpos < jend; jpos++) {
 		const int col = a.pat.bcolind[jpos];
+		const int kbeg = a.posptr[jpos], kend = a.posptr[jpos + 1];
+		if (a.skip_fixed && col > irow && kend == kbeg)
+			continue;  // an upper block without pairs: the sweep before has stored its value, a_ij
 		fd2_t s;
 		s.x = s.y = 0.0;
 		if (actB)
@@ -83,7 +86,6 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 			s.x *= a.scale[(long)irow * BS + rA] * a.scale[(long)col * BS + cA];
 			s.y *= a.scale[(long)irow * BS + rB] * a.scale[(long)col * BS + cB];
 		}
-		const int kbeg = a.posptr[jpos], kend = a.posptr[jpos + 1];
 		for (int k = kbeg; k < kend; k++) {
 			fd2_t lv, uv;
 			lv.x = lv.y = uv.x = uv.y = 0.0;

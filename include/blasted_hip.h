@@ -229,7 +229,9 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * "factorsf=0|1|2|3": the exact factorisation as one launch per dependency level (0), as one dependency-polling
  * launch where that is faster (1, default: bs >= 5, and bs = 4 with stencil-like rows through the
  * matrix-core kernel), always as one launch (2), or always as one launch of the general kernel (3); the factor
- * is the same bits in every form.  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
+ * is the same bits in every form.  "factorskip=1" (default) / "factorskip=0": in-place factorisation sweeps leave
+ * upper blocks without position pairs alone once they hold their value (the scaled matrix block), or visit
+ * every entry in every sweep.  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
  * measurement switches described where they are read (capi.hip). */
 int blasted_hip_set_tuning(const char *spec);
 

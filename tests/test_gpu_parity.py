@@ -330,6 +330,46 @@ def test_ilu_factor_async_converges_to_exact(golden, case):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["poisson16_bs4", "2dcyl1_bs4_col", "poisson9_bs8", "poisson12_bs5", "poisson16_csr"])
+@pytest.mark.parametrize("init", [capi.INIT_F_ORIGINAL, capi.INIT_F_SGS])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_factor_sweeps_leave_fixed_upper_blocks_alone(golden, case, init, usescale):
+    """In-place factorisation sweeps after the first neither read nor write an upper block without position pairs
+    (tuning "factorskip"): its value is the (scaled) matrix block from the first sweep on.  Those blocks are the
+    same bits with and without the shortcut, whatever the initial factor, and the factor converges to the exact
+    one either way."""
+    m = matrices(golden)[case]()
+    bs2 = m["bs"] ** 2
+    posptr = np.asarray(O.ilu_positions(m)[0])
+    rp = np.asarray(m["browptr"])
+    rowof = np.repeat(np.arange(m["nbrows"]), rp[1:] - rp[:-1])
+    fixed = (np.asarray(m["bcolind"]) > rowof) & (posptr[1:] == posptr[:-1])
+    assert fixed.any()
+    p = make_prec(m)
+    res = {}
+    try:
+        for k in ("1", "0"):
+            capi.set_tuning("factorskip=" + k)
+            p.ilu0_factorize(3, init=init, usescale=usescale)
+            res[k] = p.get_iluvals().reshape(-1, bs2)
+            assert np.all(np.isfinite(res[k]))
+        assert np.array_equal(res["1"][fixed], res["0"][fixed])
+        a = np.asarray(m["vals"]).reshape(-1, bs2)
+        if not usescale:
+            assert np.array_equal(res["1"][fixed], a[fixed])
+        capi.set_tuning("factorskip=1")
+        p.ilu0_factorize(90, init=init, usescale=usescale)
+        exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=usescale)["iluvals"]
+        got = p.get_iluvals().reshape(-1, bs2)
+        # (the factor is stored with inverted diagonal blocks after a factorisation: compare what the sweeps leave)
+        off = np.ones(len(got), dtype=bool)
+        off[np.asarray(m["diagind"])] = False
+        assert rel(got[off], exact.reshape(-1, bs2)[off]) < TOL_EXACT
+    finally:
+        capi.set_tuning("factorskip=1")
+    p.close()
+
+
 def test_scalar_zero_init_falls_through(golden):
     """async_ilu_factor.cpp:48-54: for bs==1 INIT_F_ZERO behaves as INIT_F_ORIGINAL."""
     m = matrices(golden)["msc_csr"]()
