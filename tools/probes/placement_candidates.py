@@ -53,6 +53,16 @@ def main():
         lo, upv = measure(p, rr, zs[0])
         print("rhs copy %d: lower %.3f ms, upper %.3f ms" % (i, lo, upv), flush=True)
     p.close()
+    # the same vectors under a NEW operator (new ytemp, new triangle copies): do they keep their mode?
+    p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
+    p.set_matrix(m)
+    p.ilu0_factorize(1, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+    p.set_timing(True)
+    third = [measure(p, r, z) for z in zs]
+    for i in range(K):
+        print("candidate %2d under a second operator: upper %.3f ms (was %.3f), lower %.3f" % (
+            i, third[i][1], first[i][1], third[i][0]), flush=True)
+    p.close()
 
 
 if __name__ == "__main__":
