@@ -184,6 +184,8 @@ void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);
 int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s);
 int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s);
+int launch_factor1_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s);
+bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream_t s);
 void launch_factor_pending_fill(const Pattern &pat, double *f, hipStream_t s);
 void set_factor_syncfree(int on);
 void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_is_indexed_by_diag,

@@ -708,6 +708,12 @@ int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s
 		return 0;
 	if (a.pat.bs > 1 && !a.diag_inverted)
 		return 0;  // (the remainder diagnostics want the un-inverted factor: per-level form)
+	if (g_factor_syncfree != 3 && a.pat.bs == 1) {
+		// stencil-like scalar rows: one lane per row, the rows of a workgroup from one level
+		const int r1 = launch_factor1_syncfree(a, ls, s);
+		if (r1 != 0)
+			return r1;
+	}
 	if (g_factor_syncfree != 3 && a.pat.bs == 4) {
 		// stencil-like rows at bs = 4: the matrix-core kernel that prepares a row before it waits
 		const int r4 = launch_factor4_syncfree(a, ls, s);

@@ -189,9 +189,204 @@ __global__ __launch_bounds__(256) void factor1_kernel(const FactorArgs a)
 	}
 }
 
+// ---- the exact scalar factorisation as one launch (round 2) ------------------------------------------------------
+// The scalar twin of sffactor4_kernel (kernels_factor4.hip, where the scheme and the row plans are described): one
+// LANE per row, the 256 rows of a workgroup from ONE dependency level, a row's plan (16 ints) and all its operands --
+// matrix values, the u_kj of its position pairs, the u_jj of its lower entries' columns, possibly still showing the
+// fill pattern -- requested up front; the wave then walks the entries in lockstep (compile-time register indices)
+// and waits, entry by entry, until every lane has what it needs.  The general single-launch kernel lets every lane
+// retry on its own and loses an order of magnitude to the divergence (scalar 64^3: 2.5 ms per level launches, 12.3 ms);
+// rows of one level never wait for each other, so here the whole wave waits for the level before.
+// Same arithmetic in the same order as the general kernels (s -= l_ik u_kj pair by pair, then s / u_jj): same bits.
+constexpr int X1_MAXE = 8, X1_MAXL = 4, X1_MAXP = 8;  // = the caps of build_row_plans
+constexpr unsigned long long X1_PENDING = 0xFFF8DEADBEEF0001ull;  // = SFF_PENDING (kernels_factor.hip)
+constexpr int X1_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ bool x1_pending(const double v)
+{
+	return (unsigned long long)__double_as_longlong(v) == X1_PENDING;
+}
+
+__device__ __forceinline__ double x1_coherent(const double *p)
+{
+	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+	                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// before the launch: diagonal + upper entries <- the fill pattern, except upper entries without position pairs, whose
+// factor value is the (scaled) matrix entry
+__global__ __launch_bounds__(256) void x1_fill_kernel(const FactorArgs a)
+{
+	const int row = blockIdx.x * 256 + threadIdx.x;
+	if (row >= a.pat.nbrows)
+		return;
+	const int dg = a.pat.diagind[row], jend = a.pat.browptr[row + 1];
+	unsigned long long *const fq = reinterpret_cast<unsigned long long *>(a.out);
+	int p0 = a.posptr[dg];
+	for (int j = dg; j < jend; j++) {
+		const int p1 = a.posptr[j + 1];
+		if (j > dg && p1 == p0) {
+			double v = a.avals[j];
+			if (a.scale) {
+				v *= a.scale[row];
+				v *= a.scale[a.pat.bcolind[j]];
+			}
+			a.out[j] = v;
+		} else
+			fq[j] = X1_PENDING;
+		p0 = p1;
+	}
+}
+
+__global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, const int4 *__restrict__ desc, int *ctl)
+{
+	double *const f = a.out;
+	const long slot = (long)blockIdx.x * 256 + threadIdx.x;  // padded position in level order
+	// the row's plan (kernels_factor4.hip: x4_describe_kernel): 0 first position, 1 row, 2..9 positions of the u_kj
+	// of its pairs, 10..13 diagonal positions of its lower entries' columns, 14 / 15 counts and pair codes
+	const int4 d0 = desc[slot * 4 + 0], d1 = desc[slot * 4 + 1], d2 = desc[slot * 4 + 2], d3 = desc[slot * 4 + 3];
+	const int jbeg = d0.x, irow = d0.y;
+	const int upo[X1_MAXP] = {d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y};
+	const int dpo[X1_MAXL] = {d2.z, d2.w, d3.x, d3.y};
+	const unsigned w14 = (unsigned)d3.z, w15 = (unsigned)d3.w;
+	const int ne = (int)(w14 & 15u), nl = (int)((w14 >> 4) & 15u), np = (int)((w14 >> 8) & 15u);
+#define X1_CODE(TT) ((TT) < 4 ? (w14 >> (12 + 5 * (TT))) : (w15 >> (5 * ((TT)-4))))
+#define X1_PQ(TT) ((TT) < np ? (int)(X1_CODE(TT) & 7u) : 8)
+#define X1_PLL(TT) ((int)((X1_CODE(TT) >> 3) & 3u))
+	unsigned pmask = 0u;  // entries with position pairs
+#pragma unroll
+	for (int tt = 0; tt < X1_MAXP; tt++)
+		pmask |= (tt < np) ? (1u << (X1_CODE(tt) & 7u)) : 0u;
+#define X1_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
+
+	double aS[X1_MAXE], uv[X1_MAXP], dv[X1_MAXL], lres[X1_MAXL];
+#pragma unroll
+	for (int q = 0; q < X1_MAXE; q++)
+		aS[q] = X1_TODO(q) ? a.avals[jbeg + q] : 0.0;
+#pragma unroll
+	for (int tt = 0; tt < X1_MAXP; tt++)
+		uv[tt] = (tt < np) ? f[upo[tt]] : 0.0;
+#pragma unroll
+	for (int q = 0; q < X1_MAXL; q++) {
+		dv[q] = (q < nl) ? f[dpo[q]] : 1.0;
+		lres[q] = 0.0;
+	}
+	if (a.scale) {
+#pragma unroll
+		for (int q = 0; q < X1_MAXE; q++)
+			if (X1_TODO(q)) {
+				aS[q] *= a.scale[irow];
+				aS[q] *= a.scale[a.pat.bcolind[jbeg + q]];
+			}
+	}
+
+	// ---- wait until everything the rows of this wave read from other rows has been published.  ONE lane polls, for
+	// the whole wave, the operand the first waiting lane misses; when that has arrived everybody re-reads coherently
+	// what still shows the fill pattern.  (Every lane re-reading its operands in a loop was the first form: thousands
+	// of resident waves polling like that saturate the memory system and stretch a dependency hop from 0.6 us --
+	// tools/probes/pingpong_probe.hip -- to 5 us.  Waiting entry by entry cost a round trip per entry.)
+	int spins = 0;
+	for (;;) {
+		const double *miss = nullptr;
+#pragma unroll
+		for (int tt = X1_MAXP - 1; tt >= 0; tt--)
+			if (tt < np && x1_pending(uv[tt]))
+				miss = f + upo[tt];
+#pragma unroll
+		for (int q = X1_MAXL - 1; q >= 0; q--)
+			if (q < nl && x1_pending(dv[q]))
+				miss = f + dpo[q];
+		const unsigned long long waiting = __builtin_amdgcn_ballot_w64(miss != nullptr);
+		if (waiting == 0ull)
+			break;
+		const int lead = __builtin_ctzll(waiting);
+		const unsigned long long addr = (unsigned long long)reinterpret_cast<uintptr_t>(miss);
+		const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)addr, lead);
+		const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(addr >> 32), lead);
+		const double *const gate = reinterpret_cast<const double *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+		while (x1_pending(x1_coherent(gate))) {
+			spins++;
+			if (spins > X1_SPIN_LIMIT ||
+			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				if ((threadIdx.x & 63) == 0)
+					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+#pragma unroll
+		for (int q = 0; q < X1_MAXL; q++)
+			if (q < nl && x1_pending(dv[q]))
+				dv[q] = x1_coherent(f + dpo[q]);
+#pragma unroll
+		for (int tt = 0; tt < X1_MAXP; tt++)
+			if (tt < np && x1_pending(uv[tt]))
+				uv[tt] = x1_coherent(f + upo[tt]);
+		if (++spins > X1_SPIN_LIMIT) {
+			if ((threadIdx.x & 63) == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+	}
+
+	// ---- the rows' recurrences, entry by entry in lockstep, on registers
+#pragma unroll
+	for (int q = 0; q < X1_MAXE; q++) {
+		if (__builtin_amdgcn_ballot_w64(q < ne) == 0ull)
+			break;
+		const bool valid = X1_TODO(q);
+		if (__builtin_amdgcn_ballot_w64(valid) == 0ull)
+			continue;
+		const bool lowerq = valid && q < nl;
+		double sv = aS[q];
+#pragma unroll
+		for (int tt = 0; tt < X1_MAXP; tt++)
+			if (X1_PQ(tt) == q) {
+				const int ll = X1_PLL(tt);
+				const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : (ll == 2 ? lres[2] : lres[3]));
+				sv -= lv * uv[tt];
+			}
+		if (q < X1_MAXL && lowerq) {
+			sv = sv / dv[q < X1_MAXL ? q : 0];
+			lres[q < X1_MAXL ? q : 0] = sv;
+		}
+		if (valid) {
+			if (lowerq)
+				f[jbeg + q] = sv;
+			else
+				__hip_atomic_store(reinterpret_cast<unsigned long long *>(f + jbeg + q),
+				                   (unsigned long long)__double_as_longlong(sv), __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+#undef X1_CODE
+#undef X1_PQ
+#undef X1_PLL
+#undef X1_TODO
+}
+
 int g_factor1_enabled = -1;
 
 }  // namespace
+
+// The exact factorisation of a scalar (CSR) matrix with stencil-like rows as one launch (see sffactor1_kernel):
+// 1 = done, 0 = does not apply, -1 = a wave gave up waiting.
+int launch_factor1_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
+{
+	if (a.pat.bs != 1 || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
+		return 0;
+	if (!build_row_plans(a, ls, 256, s))
+		return 0;
+	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+	hipLaunchKernelGGL(x1_fill_kernel, dim3((unsigned)(((long)a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(sffactor1_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
+	                   reinterpret_cast<const int4 *>(ls.f4_desc), ls.ctl);
+	BHIP_CHECK(hipGetLastError());
+	int ctl[2] = {0, 0};
+	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+	BHIP_CHECK(hipStreamSynchronize(s));
+	return ctl[1] == 0 ? 1 : -1;
+}
 
 void set_factor1_enabled(int on)
 {

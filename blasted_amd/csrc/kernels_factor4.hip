@@ -223,15 +223,15 @@ constexpr int X4_DESC = 16;
 
 __global__ __launch_bounds__(256) void x4_describe_kernel(const FactorArgs a, const int4 *__restrict__ meta,
                                                           const int2 *__restrict__ wgpos, const int nwg,
-                                                          int *__restrict__ desc)
+                                                          const int rpwg, int *__restrict__ desc)
 {
 	const long gid = (long)blockIdx.x * 256 + threadIdx.x;
 	const long slot = gid >> 4;  // padded position
 	const int t = (int)(gid & 15);
-	if (slot >= (long)nwg * 16)
+	if (slot >= (long)nwg * rpwg)
 		return;
-	const int2 wp = wgpos[slot >> 4];
-	const int pos = wp.x + (int)(slot & 15);
+	const int2 wp = wgpos[slot / rpwg];
+	const int pos = wp.x + (int)(slot % rpwg);
 	int w = 0;
 	if (pos < wp.y) {
 		const int4 md = meta[pos];
@@ -361,7 +361,61 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 #pragma unroll
 	for (int q = 0; q < X4_MAXL; q++)
 		lresA[q] = 0.0;
+	// ---- wait until everything the rows of this wave read from other rows has been published.  ONE lane polls, for
+	// the whole wave, the element the first waiting lane misses; when that has arrived everybody re-reads coherently
+	// what still shows the fill pattern.  (The first form waited entry by entry with every lane re-reading its own
+	// operands in a loop: a round trip per entry, and thousands of resident waves polling like that load the memory
+	// system enough to stretch a dependency hop from the 0.6 us of tools/probes/pingpong_probe.hip to several.)
 	int spins = 0;
+	for (;;) {
+		const double *miss = nullptr;
+		int up[X4_MAXP], dp[X4_MAXL];
+#pragma unroll
+		for (int tt = X4_MAXP - 1; tt >= 0; tt--) {
+			up[tt] = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
+			if (tt < np && x4_pending(uvD[tt]))
+				miss = f + (long)up[tt] * 16 + offD;
+		}
+#pragma unroll
+		for (int q = X4_MAXL - 1; q >= 0; q--) {
+			dp[q] = __shfl(dw, X4_SLOTLANE(10 + q), 64);
+			if (q < nl && x4_pending(dvB[q]))
+				miss = f + (long)dp[q] * 16 + offD;
+		}
+		const unsigned long long waiting = __builtin_amdgcn_ballot_w64(miss != nullptr);
+		if (waiting == 0ull)
+			break;
+		const int lead = __builtin_ctzll(waiting);
+		const unsigned long long addr = (unsigned long long)reinterpret_cast<uintptr_t>(miss);
+		const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)addr, lead);
+		const unsigned ahi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(addr >> 32), lead);
+		const double *const gate = reinterpret_cast<const double *>((uintptr_t)(((unsigned long long)ahi << 32) | alo));
+		while (x4_pending(x4_coherent(gate))) {
+			spins++;
+			if (spins > X4_SPIN_LIMIT ||
+			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				if (lane == 0)
+					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return false;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+#pragma unroll
+		for (int q = 0; q < X4_MAXL; q++)
+			if (q < nl && x4_pending(dvB[q]))
+				dvB[q] = x4_coherent(f + (long)dp[q] * 16 + offD);
+#pragma unroll
+		for (int tt = 0; tt < X4_MAXP; tt++)
+			if (tt < np && x4_pending(uvD[tt]))
+				uvD[tt] = x4_coherent(f + (long)up[tt] * 16 + offD);
+		if (++spins > X4_SPIN_LIMIT) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return false;
+		}
+	}
+
+	// ---- the rows' recurrences, entry by entry, the four slots in lockstep, on registers
 #pragma unroll
 	for (int q = 0; q < X4_MAXE; q++) {
 		if (!X4_ANY(q < ne))
@@ -370,41 +424,6 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 		if (!X4_ANY(valid))
 			continue;
 		const bool lowerq = q < nl, diagq = valid && q == nl;
-		// wait until every operand of entry q has been published
-		for (;;) {
-			bool pend = false;
-			if (q < X4_MAXL)
-				pend = lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0]);
-#pragma unroll
-			for (int tt = 0; tt < X4_MAXP; tt++)
-				if (UNI ? X4_PQ(tt) == q : true)
-					pend = pend || (X4_PQ(tt) == q && x4_pending(uvD[tt]));
-			if (__builtin_amdgcn_ballot_w64(pend) == 0ull)
-				break;
-			// the whole wave re-reads, coherently, what still shows the fill pattern (the positions come out of the
-			// plan again: they are not worth registers)
-			if (q < X4_MAXL) {
-				const int dp = __shfl(dw, X4_SLOTLANE(10 + (q < X4_MAXL ? q : 0)), 64);
-				if (lowerq && x4_pending(dvB[q < X4_MAXL ? q : 0]))
-					dvB[q < X4_MAXL ? q : 0] = x4_coherent(f + (long)dp * 16 + offD);
-			}
-#pragma unroll
-			for (int tt = 0; tt < X4_MAXP; tt++) {
-				if (!X4_ANY(X4_PQ(tt) == q))
-					continue;
-				const int up = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
-				if (X4_PQ(tt) == q && x4_pending(uvD[tt]))
-					uvD[tt] = x4_coherent(f + (long)up * 16 + offD);
-			}
-			spins++;
-			if (spins > X4_SPIN_LIMIT ||
-			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-				if (lane == 0)
-					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				return false;
-			}
-			__builtin_amdgcn_s_sleep(1);
-		}
 		// S = A - sum L U (upper / diagonal entries, D layout) or S^T = A^T - sum U^T L^T (lower entries, A layout).
 		// Pair by pair, each product summed from zero and then subtracted: the order of the general kernels
 		// (s -= group_gemm(l, u), kernels_factor.hip), so that the factor is the same bits.
@@ -485,16 +504,14 @@ int g_factor4_enabled = -1;
 
 }  // namespace
 
-// The exact factorisation of a bs = 4 matrix (either block layout) with stencil-like rows as one launch (see
-// sffactor4_kernel): 1 = done, 0 = does not apply, -1 = a wave gave up waiting.
-int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
+// Once per pattern: the longest pair list of a row, the per-level workgroup layout (rpwg rows per workgroup, every
+// level starting a new one) and the rows' plans in that padded level order.  false: the pattern's rows do not fit
+// the caps of the plan kernels (X4_MAXE entries, X4_MAXL lower ones, X4_MAXP pairs).
+bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream_t s)
 {
-	if (a.pat.bs != 4 || !a.diag_inverted || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
-		return 0;
 	if (a.pat.max_row_len > X4_MAXE || ls.max_lower > X4_MAXL)
-		return 0;
+		return false;
 	if (ls.f4_maxpairs < 0) {
-		// once per pattern: the longest pair list of a row, and the per-level workgroup layout
 		int *d = nullptr;
 		BHIP_CHECK(tracked_malloc(&d, sizeof(int)));
 		BHIP_CHECK(hipMemsetAsync(d, 0, sizeof(int), s));
@@ -508,22 +525,31 @@ int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 		if (ls.f4_maxpairs <= X4_MAXP) {
 			std::vector<int2> wg;
 			for (int l = 0; l < ls.nlevels; l++)
-				for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += 16)
-					wg.push_back(make_int2(q, std::min(q + 16, ls.ptr[(size_t)l + 1])));
+				for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += rpwg)
+					wg.push_back(make_int2(q, std::min(q + rpwg, ls.ptr[(size_t)l + 1])));
 			ls.f4_grid = (int)wg.size();
 			int2 *wgpos = nullptr;
 			BHIP_CHECK(tracked_malloc(&wgpos, sizeof(int2) * wg.size()));
 			BHIP_CHECK(hipMemcpyAsync(wgpos, wg.data(), sizeof(int2) * wg.size(), hipMemcpyHostToDevice, s));
-			const long nd = (long)ls.f4_grid * 16 * X4_DESC;
+			const long nd = (long)ls.f4_grid * rpwg * X4_DESC;
 			BHIP_CHECK(tracked_malloc(&ls.f4_desc, sizeof(int) * (size_t)nd));
 			hipLaunchKernelGGL(x4_describe_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a, ls.meta, wgpos,
-			                   ls.f4_grid, ls.f4_desc);
+			                   ls.f4_grid, rpwg, ls.f4_desc);
 			BHIP_CHECK(hipGetLastError());
 			BHIP_CHECK(hipStreamSynchronize(s));
 			(void)tracked_free(wgpos);
 		}
 	}
-	if (ls.f4_maxpairs > X4_MAXP)
+	return ls.f4_maxpairs <= X4_MAXP;
+}
+
+// The exact factorisation of a bs = 4 matrix (either block layout) with stencil-like rows as one launch (see
+// sffactor4_kernel): 1 = done, 0 = does not apply, -1 = a wave gave up waiting.
+int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s)
+{
+	if (a.pat.bs != 4 || !a.diag_inverted || a.in != a.out || !ls.built || !ls.meta || !ls.ctl)
+		return 0;
+	if (!build_row_plans(a, ls, 16, s))
 		return 0;
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 	hipLaunchKernelGGL(x4_fill_kernel, dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)), dim3(256), 0, s, a);

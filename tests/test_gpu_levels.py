@@ -176,6 +176,31 @@ def test_exact_factorisation_bs4_matrix_core_single_launch(n, scaled, rowmajor):
     p.close()
 
 
+@pytest.mark.parametrize("n,scaled", [(16, False), (13, True), (40, False)])
+def test_exact_factorisation_scalar_single_launch(n, scaled):
+    """Scalar stencil rows: the single-launch exact factorisation is the lane-per-row kernel on row plans
+    (sffactor1_kernel).  It has run, nobody gave up waiting, the factor is the per-level one bit for bit and the
+    serial one within rounding."""
+    m = W.poisson3d(n, 1)
+    p = make_prec(m)
+    before = p.level_stats()["syncfree_passes"]
+    p.ilu0_factorize(-1, usescale=scaled)
+    st = p.level_stats()
+    g = p.get_iluvals()
+    capi.set_tuning("factorsf=0")
+    try:
+        p.ilu0_factorize(-1, usescale=scaled)
+        assert np.array_equal(g, p.get_iluvals())
+    finally:
+        capi.set_tuning("factorsf=1")
+    assert st["syncfree_aborts"] == 0
+    if st["syncfree_passes"] != before:   # ("level=launch" keeps one launch per level)
+        assert st["syncfree_passes"] == before + 1
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=scaled)["iluvals"]
+    assert rel(g, f) < TOL
+    p.close()
+
+
 def test_level_schedule_nonsymmetric_pattern(golden):
     m = one_sided(W.poisson3d(10, 4))
     p = make_prec(m)
