@@ -14,6 +14,10 @@
 //    kernels_level.hip for the forward-progress argument and the bounded-spin abort).
 // Rows of one step may depend on each other across a level boundary, so a row is committed as soon as
 // ITS lanes have everything and the wave loops until all its rows are done.
+// (Round 2, tried here after it had paid in the single-launch factorisation kernels: one lane polling one missing
+// entry for the whole wave before everybody re-reads.  A row of a solve misses at most four 8-byte entries, the gate
+// is one more dependent round trip, and the exact apply got slower: 256^3 bs=4 5.76 -> 5.96 ms, 100^3 bs=8 1.39 ->
+// 1.51, 64^3 0.69 -> 0.75.  Not kept.)
 #include "ctx.hpp"
 #include "lanes.hpp"
 
