@@ -182,12 +182,13 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 // register indices).  For stencil-like rows only: at most X4_MAXE entries, X4_MAXL of them lower, X4_MAXP position
 // pairs per row; other patterns take the general kernel.
 // Measured (MI355X, ms per exact factorisation, one launch per level -> general single launch -> this):
-//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 11.5;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.6.
+//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 10.1;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.3.
 // How it got there, at 256^3: first form (indices through the matrix's own arrays, level of a workgroup by binary
 // search) 17.8; per-workgroup table 14.6; row plans 13.3; shape in scalar registers where the four rows agree
-// 13.0; upper blocks without pairs stored by the fill pass instead 11.5.  With nobody waiting (wrong factor,
-// experiment) the same launches take 10.4: the dependency chain costs about a millisecond, the rest is the rate at
-// which four waves per SIMD (110 registers, 80 of them operand blocks) turn rows over.  Tried and dropped: a
+// 13.0; upper blocks without pairs stored by the fill pass instead 11.5; one wait per row with a single polling
+// lane per wave (x4_rows) 10.1.  With nobody waiting (wrong factor, experiment) the launches took 10.4 when the real
+// ones took 11.5: the rest is the rate at which four waves per SIMD (124 registers, 80 of them operand blocks) turn
+// rows over.  Tried and dropped: a
 // resident grid whose waves walk the units with the next plan requested ahead (15.5 against 14.1 for the form it
 // was tried on); five waves per SIMD by register bound (spills: 31 ms); re-reading the pending operands of LATER
 // entries while waiting for the current one (no change).
