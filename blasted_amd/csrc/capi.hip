@@ -1779,7 +1779,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "factorskip=", 11) == 0)
 			g_factor_skip_fixed = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "factorsf=", 9) == 0)
-			set_factor_syncfree(spec[9] - '0');
+			set_factor_syncfree(spec[9] == 'p' ? 10 + (spec[10] - '0') : spec[9] - '0');
 		else if (spec && std::strncmp(spec, "factor1=", 8) == 0)
 			set_factor1_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)

@@ -682,12 +682,211 @@ __global__ __launch_bounds__(256) void sff_factor_kernel(const FactorArgs a, con
 	}
 }
 
+// ---- the exact factorisation as one launch on ROW PLANS, any block size with at least 16 lanes per row (3 ... 8)
+// The lane layout and the arithmetic of factor_sweep_kernel (lane (r,c) of a group holds entry (r,c) of every block;
+// products and inverses through the group's shuffles: the same bits), the waiting scheme of sffactor4_kernel
+// (kernels_factor4.hip, where it is described): a row's plan is one 64-byte record in padded level order, all its
+// operands are requested up front, a wave waits ONCE for what its rows read from other rows with one lane polling
+// one element, and the recurrence then runs on registers.  The kernel above walks a row entry by entry through
+// three to four dependent index and operand round trips each: 18 us per level at 100^3 bs=8.
+// Stencil-like rows only (the caps of build_row_plans); the rows of a workgroup come from one level.
+constexpr int XP_MAXE = 8, XP_MAXL = 4, XP_MAXP = 8;
+
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void sffplan_fill_kernel(const FactorArgs a)
+{
+	constexpr int BS2 = BS * BS;
+	const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+	const int t = threadIdx.x & 15;
+	if (row >= a.pat.nbrows)
+		return;
+	const int dg = a.pat.diagind[row], jend = a.pat.browptr[row + 1];
+	unsigned long long *const fq = reinterpret_cast<unsigned long long *>(a.out);
+	int p0 = a.posptr[dg];
+	for (int j = dg; j < jend; j++) {
+		const int p1 = a.posptr[j + 1];
+		if (j > dg && p1 == p0) {
+			// an upper block without position pairs: its factor value is the (scaled) matrix block
+			const int col = a.scale ? a.pat.bcolind[j] : 0;
+			for (int e = t; e < BS2; e += 16) {
+				double v = a.avals[(long)j * BS2 + e];
+				if (a.scale) {
+					const int r = RM ? e / BS : e % BS, c = RM ? e % BS : e / BS;
+					v *= a.scale[(long)row * BS + r] * a.scale[(long)col * BS + c];
+				}
+				a.out[(long)j * BS2 + e] = v;
+			}
+		} else
+			for (int e = t; e < BS2; e += 16)
+				fq[(long)j * BS2 + e] = SFF_PENDING;
+		p0 = p1;
+	}
+}
+
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
+{
+	using Ge = FGeo<BS>;
+	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
+	static_assert(SUB >= 16, "a row's plan is read by 16 lanes of its group");
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane / SUB, u = lane % SUB;
+	const int r = u % BSP, c = u / BSP;
+	const bool active = (r < BS) && (c < BS);
+	const int e = RM ? r * BS + c : c * BS + r;
+	const int gbase = lane & ~(SUB - 1);
+	double *const f = a.out;
+
+	const long slot = (long)blockIdx.x * Ge::RPB + wave * Ge::RPW + g;  // padded position in level order
+	const int dw = (u < 16) ? desc[slot * 16 + u] : 0;
+	const int jbeg = __shfl(dw, gbase + 0, 64), irow = __shfl(dw, gbase + 1, 64);
+	const unsigned w14 = (unsigned)__shfl(dw, gbase + 14, 64), w15 = (unsigned)__shfl(dw, gbase + 15, 64);
+	const int ne = (int)(w14 & 15u), nl = (int)((w14 >> 4) & 15u), np = (int)((w14 >> 8) & 15u);
+#define XP_CODE(TT) ((TT) < 4 ? (w14 >> (12 + 5 * (TT))) : (w15 >> (5 * ((TT)-4))))
+#define XP_PQ(TT) ((TT) < np ? (int)(XP_CODE(TT) & 7u) : 8)
+#define XP_PLL(TT) ((int)((XP_CODE(TT) >> 3) & 3u))
+	unsigned pmask = 0u;  // entries with position pairs; an upper entry without any has been stored by the fill pass
+#pragma unroll
+	for (int tt = 0; tt < XP_MAXP; tt++)
+		pmask |= (tt < np) ? (1u << (XP_CODE(tt) & 7u)) : 0u;
+#define XP_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
+
+	// ---- operands; blocks of other rows may still show the fill pattern
+	double aS[XP_MAXE], uv[XP_MAXP], dv[XP_MAXL], lres[XP_MAXL];
+	int upo[XP_MAXP], dpo[XP_MAXL];
+#pragma unroll
+	for (int q = 0; q < XP_MAXE; q++)
+		aS[q] = (XP_TODO(q) && active) ? a.avals[(long)(jbeg + q) * BS2 + e] : 0.0;
+#pragma unroll
+	for (int tt = 0; tt < XP_MAXP; tt++) {
+		upo[tt] = __shfl(dw, gbase + 2 + tt, 64);
+		uv[tt] = (tt < np && active) ? f[(long)upo[tt] * BS2 + e] : 0.0;
+	}
+#pragma unroll
+	for (int q = 0; q < XP_MAXL; q++) {
+		dpo[q] = __shfl(dw, gbase + 10 + q, 64);
+		dv[q] = (q < nl && active) ? f[(long)dpo[q] * BS2 + e] : 0.0;
+		lres[q] = 0.0;
+	}
+	if (a.scale) {
+#pragma unroll
+		for (int q = 0; q < XP_MAXE; q++)
+			if (XP_TODO(q) && active) {
+				const int col = a.pat.bcolind[jbeg + q];
+				aS[q] *= a.scale[(long)irow * BS + r] * a.scale[(long)col * BS + c];
+			}
+	}
+
+	// ---- one wait for everything; one lane polls one element for the whole wave (see x4_rows)
+	int spins = 0;
+	for (;;) {
+		const double *miss = nullptr;
+#pragma unroll
+		for (int tt = XP_MAXP - 1; tt >= 0; tt--)
+			if (tt < np && sff_pending(uv[tt]))
+				miss = f + (long)upo[tt] * BS2 + e;
+#pragma unroll
+		for (int q = XP_MAXL - 1; q >= 0; q--)
+			if (q < nl && sff_pending(dv[q]))
+				miss = f + (long)dpo[q] * BS2 + e;
+		const unsigned long long waiting = __builtin_amdgcn_ballot_w64(miss != nullptr);
+		if (waiting == 0ull)
+			break;
+		const int lead = __builtin_ctzll(waiting);
+		const unsigned long long addr = (unsigned long long)reinterpret_cast<uintptr_t>(miss);
+		const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)addr, lead);
+		const unsigned ahi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(addr >> 32), lead);
+		const double *const gate = reinterpret_cast<const double *>((uintptr_t)(((unsigned long long)ahi << 32) | alo));
+		for (;;) {
+			const double gv = __longlong_as_double((long long)__hip_atomic_load(
+			    reinterpret_cast<const unsigned long long *>(gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			if (!sff_pending(gv))
+				break;
+			spins++;
+			if (spins > SFF_SPIN_LIMIT ||
+			    ((spins & 255) == 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				if (lane == 0)
+					__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+#pragma unroll
+		for (int q = 0; q < XP_MAXL; q++)
+			if (q < nl && sff_pending(dv[q]))
+				dv[q] = __longlong_as_double((long long)__hip_atomic_load(
+				    reinterpret_cast<const unsigned long long *>(f + (long)dpo[q] * BS2 + e), __ATOMIC_RELAXED,
+				    __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+		for (int tt = 0; tt < XP_MAXP; tt++)
+			if (tt < np && sff_pending(uv[tt]))
+				uv[tt] = __longlong_as_double((long long)__hip_atomic_load(
+				    reinterpret_cast<const unsigned long long *>(f + (long)upo[tt] * BS2 + e), __ATOMIC_RELAXED,
+				    __HIP_MEMORY_SCOPE_AGENT));
+		if (++spins > SFF_SPIN_LIMIT) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+	}
+
+	// ---- the rows' recurrences on registers, entry by entry, the groups of a wave in lockstep (the group
+	// products exchange lanes: no divergence around them)
+#pragma unroll
+	for (int q = 0; q < XP_MAXE; q++) {
+		if (__builtin_amdgcn_ballot_w64(q < ne) == 0ull)
+			break;
+		const bool valid = XP_TODO(q);
+		if (__builtin_amdgcn_ballot_w64(valid) == 0ull)
+			continue;
+		double sv = aS[q];
+#pragma unroll
+		for (int tt = 0; tt < XP_MAXP; tt++) {
+			const bool in = valid && XP_PQ(tt) == q;
+			if (__builtin_amdgcn_ballot_w64(in) == 0ull)
+				continue;
+			const int ll = XP_PLL(tt);
+			const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : (ll == 2 ? lres[2] : lres[3]));
+			sv -= group_gemm<BS, BSP>(in ? lv : 0.0, in ? uv[tt] : 0.0, gbase, r, c);
+		}
+		const bool lowerq = valid && q < nl, diagq = valid && q == nl;
+		if (q < XP_MAXL && __builtin_amdgcn_ballot_w64(lowerq) != 0ull) {
+			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
+			const double prod = group_gemm<BS, BSP>(lowerq ? sv : 0.0, lowerq ? dv[q < XP_MAXL ? q : 0] : 0.0, gbase, r, c);
+			if (lowerq) {
+				sv = prod;
+				lres[q < XP_MAXL ? q : 0] = prod;
+			}
+		}
+		if (q <= XP_MAXL && __builtin_amdgcn_ballot_w64(diagq) != 0ull) {
+			const double inv = group_inverse<BS, BSP>(diagq ? sv : ((r == c) ? 1.0 : 0.0), gbase, r, c);
+			if (diagq)
+				sv = inv;
+		}
+		if (valid && active) {
+			double *const dst = f + (long)(jbeg + q) * BS2 + e;
+			if (lowerq)
+				*dst = sv;  // read by this row (from registers) and by the triangular solves later
+			else
+				sff_publish(dst, sv);
+		}
+	}
+#undef XP_CODE
+#undef XP_PQ
+#undef XP_PLL
+#undef XP_TODO
+}
+
 // tuning "factorsf=0|1|2|3": one launch per level | one launch where it pays | always one launch | always one
 // launch of the general kernel (no matrix-core kernel at bs = 4); the factor is the same bits in every form
 static int g_factor_syncfree = 1;
+static int g_factor_plan = 1;  // "factorsf=p0|p1": plan kernel for block sizes other than 1 and 4 off | on
 void set_factor_syncfree(int on)
 {
-	g_factor_syncfree = on;
+	if (on >= 10)
+		g_factor_plan = on - 10;
+	else
+		g_factor_syncfree = on;
 }
 
 // diagonal + upper blocks of the factor <- the pending pattern (before a single-launch exact factorisation)
@@ -713,6 +912,26 @@ int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s
 		const int r1 = launch_factor1_syncfree(a, ls, s);
 		if (r1 != 0)
 			return r1;
+	}
+	if (g_factor_syncfree != 3 && a.pat.bs != 1 && a.pat.bs != 4 && a.pat.bs != 2 && g_factor_plan) {
+		// stencil-like rows: the plan kernel in the general lane layout
+		if (build_row_plans(a, ls, a.pat.bs == 3 ? 16 : 4, s)) {
+			BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
+			BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
+				if constexpr (FGeo<BS>::SUB >= 16) {
+					static_assert(BS == 3 ? FGeo<BS>::RPB == 16 : FGeo<BS>::RPB == 4 || BS < 3 || BS == 4, "rows per workgroup");
+					hipLaunchKernelGGL((sffplan_fill_kernel<BS, RM>), dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)),
+					                   dim3(256), 0, s, a);
+					hipLaunchKernelGGL((sffplan_kernel<BS, RM>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc,
+					                   ls.ctl);
+				}
+			})
+			BHIP_CHECK(hipGetLastError());
+			int ctl[2] = {0, 0};
+			BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+			BHIP_CHECK(hipStreamSynchronize(s));
+			return ctl[1] == 0 ? 1 : -1;
+		}
 	}
 	if (g_factor_syncfree != 3 && a.pat.bs == 4) {
 		// stencil-like rows at bs = 4: the matrix-core kernel that prepares a row before it waits

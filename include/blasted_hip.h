@@ -227,9 +227,10 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * "levelwide=0" keeps the general single-launch kernel also for column-major bs 4 / 8; "sfonestep=0"
  * lets a wave of that kernel prefetch several row steps instead of one.
  * "factorsf=0|1|2|3": the exact factorisation as one launch per dependency level (0), as one dependency-polling
- * launch where that is faster (1, default: bs >= 5, and bs = 4 with stencil-like rows through the
- * matrix-core kernel), always as one launch (2), or always as one launch of the general kernel (3); the factor
- * is the same bits in every form.  "factorskip=1" (default) / "factorskip=0": in-place factorisation sweeps leave
+ * launch where that is faster (1, default: stencil-like rows of any block size but 2 through the plan kernels --
+ * matrix-core at bs = 4, lane-per-row at bs = 1 -- and bs >= 5 in general), always as one launch (2), or always as
+ * one launch of the general kernel (3); the factor is the same bits in every form.  "factorsf=p0" keeps the plan
+ * kernel of block sizes 3, 5, 7, 8 off.  "factorskip=1" (default) / "factorskip=0": in-place factorisation sweeps leave
  * upper blocks without position pairs alone once they hold their value (the scaled matrix block), or visit
  * every entry in every sweep.  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
  * measurement switches described where they are read (capi.hip). */
