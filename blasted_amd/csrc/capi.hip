@@ -1748,6 +1748,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)
+			set_level_fast(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelserial=", 12) == 0)
 			set_level_serial_after(std::atol(spec + 12));
 		else if (spec && std::strncmp(spec, "levelstore=", 11) == 0)

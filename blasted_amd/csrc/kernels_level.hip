@@ -78,6 +78,109 @@ __global__ __launch_bounds__(256) void level_relax_kernel(const Pattern pat, int
 		*changed = 1;
 }
 
+// The levels of a pattern whose dependencies are all STORED as lower entries (a structurally symmetric pattern),
+// in one launch: one lane per row in natural order, a row waits for the levels of its lower neighbours -- pre-filled
+// with -1 -- and publishes 1 + their maximum.  Neighbours inside the same wave (the x-line of a stencil: a chain of
+// 64) are read through lane exchanges, so a chain inside a wave costs an exchange per link instead of a memory
+// round trip; lanes never block (a row of the wave may wait for another), the wave loops until all its rows are
+// done.  Workgroups are started in row order, a row waits for earlier rows only.  256^3: one launch instead of 328
+// relaxation passes (round 2: 158 ms for the schedule of the headline matrix, 130 of them those passes).
+constexpr int LVF_SPIN_LIMIT = 1 << 22;
+
+__global__ __launch_bounds__(256) void level_poll_kernel(const Pattern pat, int *level, int *ctl)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int wbase = i - lane;  // first row of this wave
+	const bool rowok = i < pat.nbrows;
+	const int rbeg = rowok ? pat.browptr[i] : 0;
+	const int nlow = rowok ? pat.diagind[i] - rbeg : 0;  // (columns ascend: the lower entries come first)
+	int nmax = nlow;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const int o = __shfl_xor(nmax, off, 64);
+		nmax = o > nmax ? o : nmax;
+	}
+	// the first eight lower neighbours live in registers (a chain inside the wave is walked without memory operations)
+	constexpr int NREG = 8;
+	int cj[NREG];
+#pragma unroll
+	for (int q = 0; q < NREG; q++)
+		cj[q] = q < nlow ? pat.bcolind[rbeg + q] : wbase;
+	int lv = rowok ? -1 : 0;
+	int mext = 0;          // 1 + the highest level among the neighbours outside the wave seen so far
+	unsigned seen = 0u;    // those neighbours (the first 32 entries of the row) that have been seen: not read again
+	int spins = 0;
+	for (;;) {
+		// one attempt per lane; the loops over a row's lower entries are wave-uniform because of the lane exchange in them
+		bool ready = lv < 0;
+		int m = mext;
+#pragma unroll
+		for (int q = 0; q < NREG; q++) {
+			if (q >= nmax)
+				break;
+			const bool has = q < nlow && lv < 0;
+			const int j = cj[q];
+			const int inw = __shfl(lv, (j - wbase) & 63, 64);  // its level if it is a row of this wave
+			if (!has)
+				continue;
+			int dj;
+			if (j >= wbase)
+				dj = inw;
+			else if ((seen >> q) & 1u)
+				continue;
+			else {
+				dj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (dj >= 0) {
+					mext = dj + 1 > mext ? dj + 1 : mext;
+					seen |= 1u << q;
+				}
+			}
+			if (dj < 0)
+				ready = false;
+			else
+				m = dj + 1 > m ? dj + 1 : m;
+		}
+		for (int q = NREG; q < nmax; q++) {
+			const bool has = q < nlow && lv < 0;
+			const int j = has ? pat.bcolind[rbeg + q] : wbase;
+			const int inw = __shfl(lv, (j - wbase) & 63, 64);
+			if (!has)
+				continue;
+			int dj;
+			if (j >= wbase)
+				dj = inw;
+			else if (q < 32 && ((seen >> q) & 1u))
+				continue;
+			else {
+				dj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (dj >= 0) {
+					mext = dj + 1 > mext ? dj + 1 : mext;
+					if (q < 32)
+						seen |= 1u << q;
+				}
+			}
+			if (dj < 0)
+				ready = false;
+			else
+				m = dj + 1 > m ? dj + 1 : m;
+		}
+		if (lv < 0 && ready) {
+			lv = m;
+			__hip_atomic_store(&level[i], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (__builtin_amdgcn_ballot_w64(lv < 0) == 0ull)
+			return;
+		spins++;
+		if (spins > LVF_SPIN_LIMIT ||
+		    ((spins & 255) == 0 && __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			if (lane == 0)
+				__hip_atomic_store(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+	}
+}
+
 // The same fixed point by ONE wave walking the rows in order: row i's level is final once rows < i are, so one
 // pass is exact whatever the depth of the dependency graph -- O(nnz) work on a ~2 us dependent step per row.
 // The fall-back for patterns whose depth is of the order of the row count (banded, one-dimensional orderings),
@@ -266,13 +369,25 @@ __global__ __launch_bounds__(256) void level_meta_kernel(const Pattern pat, cons
                                                          int *lens)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
-	if (k >= pat.nbrows)
-		return;
-	const int row = rows[k];
-	const int rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
-	meta[k] = make_int4(row, rp0, dg, rp1);
-	atomicMax(lens, dg - rp0);
-	atomicMax(lens + 1, rp1 - dg - 1);
+	int nlow = 0, nup = 0;
+	if (k < pat.nbrows) {
+		const int row = rows[k];
+		const int rp0 = pat.browptr[row], rp1 = pat.browptr[row + 1], dg = pat.diagind[row];
+		meta[k] = make_int4(row, rp0, dg, rp1);
+		nlow = dg - rp0;
+		nup = rp1 - dg - 1;
+	}
+	// one atomic per wave (one per lane made this kernel six times slower than its loads)
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const int a = __shfl_xor(nlow, off, 64), b = __shfl_xor(nup, off, 64);
+		nlow = a > nlow ? a : nlow;
+		nup = b > nup ? b : nup;
+	}
+	if ((threadIdx.x & 63) == 0) {
+		atomicMax(lens, nlow);
+		atomicMax(lens + 1, nup);
+	}
 }
 
 constexpr unsigned long long SF_PENDING = 0xFFF8DEADBEEF0001ull;  // a NaN payload arithmetic never produces
@@ -640,6 +755,13 @@ T *lvl_alloc(size_t count)
 
 }  // namespace
 
+// tuning ("levelfast=0|1"): the level-schedule build starts with the dependency-polling launch (default) or not
+int g_level_fast = 1;
+void set_level_fast(int on)
+{
+	g_level_fast = on;
+}
+
 // tuning ("levelserial=N"): parallel relaxation passes of the level-schedule build before the in-order fall-back
 long g_level_serial_after = 4096;
 void set_level_serial_after(long n)
@@ -686,12 +808,30 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 	int *dptr = nullptr;
 	void *tmp = nullptr;
 	try {
-		BHIP_CHECK(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, s));
 		constexpr int BATCH = 8;
 		flags = lvl_alloc<int>(BATCH);
 		int hflags[BATCH];
 		bool fixed = false;
 		long passes = 0;
+		bool have_start = false;
+		if (g_level_fast) {
+			// one dependency-polling launch over the stored lower entries, then one relaxation pass: on a structurally
+			// symmetric pattern it changes nothing and the levels are final; otherwise (dependencies implied by upper
+			// entries only) the passes below continue from here -- every level found so far is a lower bound
+			BHIP_CHECK(hipMemsetAsync(level, 0xff, sizeof(int) * (size_t)n, s));
+			BHIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * BATCH, s));
+			hipLaunchKernelGGL(level_poll_kernel, dim3(grid), dim3(256), 0, s, pat, level, flags);
+			hipLaunchKernelGGL(level_relax_kernel, dim3(grid), dim3(256), 0, s, pat, level, flags + 1);
+			BHIP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+			BHIP_CHECK(hipStreamSynchronize(s));
+			if (hflags[0] == 0) {  // (nobody gave up waiting)
+				have_start = true;
+				passes = 2;
+				fixed = hflags[1] == 0;
+			}
+		}
+		if (!have_start)
+			BHIP_CHECK(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, s));
 		// beyond this many passes (= dependency levels) the parallel relaxation loses to one in-order pass
 		const long serial_after = g_level_serial_after;
 		for (long done = 0; done < (long)n + 2 && !fixed && passes < serial_after; done += BATCH) {
