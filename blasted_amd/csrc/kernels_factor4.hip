@@ -528,6 +528,12 @@ bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream
 			for (int l = 0; l < ls.nlevels; l++)
 				for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += rpwg)
 					wg.push_back(make_int2(q, std::min(q + rpwg, ls.ptr[(size_t)l + 1])));
+			if ((long)wg.size() * rpwg > 2L * a.pat.nbrows + 4096) {
+				// narrow levels (a banded / one-dimensional ordering): padding every level to a workgroup would
+				// multiply the plan array -- such a pattern keeps the kernels that take rows as they come
+				ls.f4_maxpairs = 1 << 30;
+				return false;
+			}
 			ls.f4_grid = (int)wg.size();
 			int2 *wgpos = nullptr;
 			BHIP_CHECK(tracked_malloc(&wgpos, sizeof(int2) * wg.size()));

@@ -211,6 +211,35 @@ def test_exact_factorisation_scalar_single_launch(n, scaled):
     p.close()
 
 
+def test_exact_factorisation_narrow_levels_keep_the_general_kernels():
+    """A one-dimensional ordering (levels = rows): padding every level to a workgroup would multiply the plan array,
+    so the plan kernels decline and the factorisation still is the serial one (scalar and bs = 4)."""
+    n = 2500
+    for bs in (1, 4):
+        rows = np.repeat(np.arange(n), 3)
+        cols = (rows.reshape(n, 3) + np.array([-1, 0, 1])).reshape(-1)
+        keep = (cols >= 0) & (cols < n)
+        rows, cols = rows[keep], cols[keep]
+        rp = np.zeros(n + 1, np.int32)
+        np.add.at(rp, rows + 1, 1)
+        rp = np.cumsum(rp).astype(np.int32)
+        rng = np.random.default_rng(17)
+        vals = rng.uniform(-0.2, 0.2, (rows.size, bs * bs))
+        vals[rows == cols] = (2.0 * np.eye(bs) + 0.05).reshape(-1)
+        m = dict(nbrows=n, nnzb=int(rows.size), bs=bs, rowmajor=False, browptr=rp, bcolind=cols.astype(np.int32),
+                 diagind=np.nonzero(rows == cols)[0].astype(np.int32), vals=np.ascontiguousarray(vals.reshape(-1)))
+        p = make_prec(m)
+        p.level_count()
+        before = p.memory_stats()["bytes"]
+        p.ilu0_factorize(-1)
+        assert p.level_stats()["levels"] == n
+        # no plan array: 64 bytes per row of a level padded to 16 (bs = 4) or 256 (scalar) rows would be n * 1 KB / 16 KB
+        assert p.memory_stats()["bytes"] - before < n * 600 + (1 << 20)
+        f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+        assert rel(p.get_iluvals(), f) < TOL
+        p.close()
+
+
 def test_level_schedule_nonsymmetric_pattern(golden):
     m = one_sided(W.poisson3d(10, 4))
     p = make_prec(m)
