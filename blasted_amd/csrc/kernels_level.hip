@@ -115,31 +115,39 @@ __global__ __launch_bounds__(256) void level_poll_kernel(const Pattern pat, int 
 		// one attempt per lane; the loops over a row's lower entries are wave-uniform because of the lane exchange in them
 		bool ready = lv < 0;
 		int m = mext;
+		// neighbours inside the wave first (lane exchanges only) ...
 #pragma unroll
 		for (int q = 0; q < NREG; q++) {
 			if (q >= nmax)
 				break;
-			const bool has = q < nlow && lv < 0;
 			const int j = cj[q];
 			const int inw = __shfl(lv, (j - wbase) & 63, 64);  // its level if it is a row of this wave
-			if (!has)
-				continue;
-			int dj;
-			if (j >= wbase)
-				dj = inw;
-			else if ((seen >> q) & 1u)
-				continue;
-			else {
-				dj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (q < nlow && lv < 0 && j >= wbase) {
+				if (inw < 0)
+					ready = false;
+				else
+					m = inw + 1 > m ? inw + 1 : m;
+			}
+		}
+		// ... and the others are asked for only by a row that has those: along a chain inside the wave that is one
+		// lane at a time instead of sixty-four lanes polling on every round
+		const bool ask = ready || (spins & 7) == 0;  // (and everybody now and then: what is there early is seen early)
+#pragma unroll
+		for (int q = 0; q < NREG; q++) {
+			if (q >= nmax)
+				break;
+			const int j = cj[q];
+			if (q < nlow && lv < 0 && j < wbase && !((seen >> q) & 1u)) {
+				int dj = -1;
+				if (ask)
+					dj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (dj >= 0) {
 					mext = dj + 1 > mext ? dj + 1 : mext;
+					m = dj + 1 > m ? dj + 1 : m;
 					seen |= 1u << q;
-				}
+				} else
+					ready = false;
 			}
-			if (dj < 0)
-				ready = false;
-			else
-				m = dj + 1 > m ? dj + 1 : m;
 		}
 		for (int q = NREG; q < nmax; q++) {
 			const bool has = q < nlow && lv < 0;
