@@ -1749,7 +1749,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
 		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)
-			set_level_fast(spec[10] != '0');
+			set_level_fast(spec[10] - '0');  // (2: tests -- behave as if the polling launch had given up)
 		else if (spec && std::strncmp(spec, "levelserial=", 12) == 0)
 			set_level_serial_after(std::atol(spec + 12));
 		else if (spec && std::strncmp(spec, "levelstore=", 11) == 0)
@@ -1781,7 +1781,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "factorskip=", 11) == 0)
 			g_factor_skip_fixed = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "factorsf=", 9) == 0)
-			set_factor_syncfree(spec[9] == 'p' ? 10 + (spec[10] - '0') : spec[9] - '0');
+			set_factor_syncfree(spec[9] == 'p' ? 10 + (spec[10] - '0') : (spec[9] == 'a' ? 20 + (spec[10] - '0') : spec[9] - '0'));
 		else if (spec && std::strncmp(spec, "factor1=", 8) == 0)
 			set_factor1_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)

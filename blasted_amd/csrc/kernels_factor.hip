@@ -881,9 +881,12 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 // launch of the general kernel (no matrix-core kernel at bs = 4); the factor is the same bits in every form
 static int g_factor_syncfree = 1;
 static int g_factor_plan = 1;  // "factorsf=p0|p1": plan kernel for block sizes other than 1 and 4 off | on
+static int g_factor_fake_abort = 0;  // "factorsf=a1": tests -- behave as if a wave had given up waiting
 void set_factor_syncfree(int on)
 {
-	if (on >= 10)
+	if (on >= 20)
+		g_factor_fake_abort = on - 20;
+	else if (on >= 10)
 		g_factor_plan = on - 10;
 	else
 		g_factor_syncfree = on;
@@ -907,6 +910,11 @@ int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s
 		return 0;
 	if (a.pat.bs > 1 && !a.diag_inverted)
 		return 0;  // (the remainder diagnostics want the un-inverted factor: per-level form)
+	if (g_factor_fake_abort) {
+		// what an attempt that gave up leaves behind at worst: the fill pattern all over the diagonal + upper part
+		launch_factor_pending_fill(a.pat, a.out, s);
+		return -1;
+	}
 	if (g_factor_syncfree != 3 && a.pat.bs == 1) {
 		// stencil-like scalar rows: one lane per row, the rows of a workgroup from one level
 		const int r1 = launch_factor1_syncfree(a, ls, s);

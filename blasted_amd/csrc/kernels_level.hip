@@ -832,7 +832,7 @@ void build_level_schedule(const Pattern &pat, LevelSchedule &ls, hipStream_t s)
 			hipLaunchKernelGGL(level_relax_kernel, dim3(grid), dim3(256), 0, s, pat, level, flags + 1);
 			BHIP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
 			BHIP_CHECK(hipStreamSynchronize(s));
-			if (hflags[0] == 0) {  // (nobody gave up waiting)
+			if (hflags[0] == 0 && g_level_fast != 2) {  // (nobody gave up waiting)
 				have_start = true;
 				passes = 2;
 				fixed = hflags[1] == 0;

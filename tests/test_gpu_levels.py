@@ -240,6 +240,46 @@ def test_exact_factorisation_narrow_levels_keep_the_general_kernels():
         p.close()
 
 
+@pytest.mark.parametrize("case", ["poisson16_bs4", "poisson16_csr", "poisson9_bs8", "2dcyl1_bs4_row", "random_bs5"])
+def test_exact_factorisation_falls_back_when_a_wave_gives_up(golden, case):
+    """The single-launch factorisations bound their spins; a wave that runs out raises a flag and the host redoes
+    the factorisation with one launch per level, whatever the attempt left behind.  Forced here (tuning
+    "factorsf=a1": the attempt leaves the fill pattern all over the diagonal + upper part and reports failure):
+    the factor is the usual one bit for bit and the give-up is counted."""
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    p.ilu0_factorize(-1)
+    f0 = p.get_iluvals()
+    before = p.level_stats()
+    capi.set_tuning("factorsf=a1")
+    try:
+        p.ilu0_factorize(-1)
+        f1 = p.get_iluvals()
+        st = p.level_stats()
+    finally:
+        capi.set_tuning("factorsf=a0")
+    assert np.all(np.isfinite(f1)) and np.array_equal(f0, f1)
+    if st["syncfree_passes"] != before["syncfree_passes"]:   # ("level=launch" never tries the single launch)
+        assert st["syncfree_aborts"] == before["syncfree_aborts"] + 1
+    p.close()
+
+
+def test_level_schedule_falls_back_when_the_polling_launch_gives_up():
+    """The same for the level-schedule build (tuning "levelfast=2": the polling launch's result is thrown away as if
+    it had given up): the relaxation passes find the same levels from scratch."""
+    m = W.poisson3d(14, 4)
+    ref = W.dependency_levels(m)
+    capi.set_tuning("levelfast=2")
+    try:
+        p = make_prec(m)
+        lv, _, _ = p.get_levels()
+        st = p.level_stats()
+    finally:
+        capi.set_tuning("levelfast=1")
+    assert np.array_equal(lv, ref) and st["build_passes"] > 2
+    p.close()
+
+
 def test_level_schedule_nonsymmetric_pattern(golden):
     m = one_sided(W.poisson3d(10, 4))
     p = make_prec(m)
