@@ -37,11 +37,11 @@
 
 namespace bhip {
 
-template <int BS, bool RM, int PART, int POST, int DSRC, int UNR>
+template <int BS, bool RM, int PART, int POST, int DSRC, int UNR, bool BIG = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
-	static_assert((Geo<BS>::RCHUNK / Geo<BS>::RSTEP) % UNR == 0, "row steps per chunk must be a multiple of UNR");
-	using Ge = Geo<BS>;
+	static_assert((Geo<BS, BIG>::RCHUNK / Geo<BS, BIG>::RSTEP) % UNR == 0, "row steps per chunk must be a multiple of UNR");
+	using Ge = Geo<BS, BIG>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
 	constexpr int RPW = Ge::RPW, RSTEP = Ge::RSTEP, RCHUNK = Ge::RCHUNK, CAP = Ge::CAP;
 	// straight-line passes: enough for a 7-point row's lower part or diagonal + upper part, twice as
@@ -216,11 +216,16 @@ static void dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, hi
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + Geo<BS>::RCHUNK - 1) / Geo<BS>::RCHUNK);
 	if (grid == 0)
 		return;
+	// scalar rows, many of them: 256 rows per workgroup (sweep_geo.hpp)
+	const bool big = BS == 1 && a.pat.nbrows >= (1 << 20);
+	const unsigned gridbig = (unsigned)(((long)a.pat.nbrows + Geo<BS, true>::RCHUNK - 1) / Geo<BS, true>::RCHUNK);
 #define BHIP_CASE(P, Q, D)                                                                       \
 	if (part == P && post == Q && dsrc == D) {                                                   \
 		/* one block-row per wave (bs >= 5): two row steps in flight for the triangular sweeps */ \
 		constexpr int U = (Geo<BS>::G == 64 && (P == PART_LOWER || P == PART_UPPER)) ? 2 : 1;    \
-		if (g_sweep_unroll == 1)                                                                 \
+		if (BS == 1 && big && g_sweep_unroll != 1)                                               \
+			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, U, BS == 1>), dim3(gridbig), dim3(256), 0, s, a); \
+		else if (g_sweep_unroll == 1)                                                            \
 			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, 1>), dim3(grid), dim3(256), 0, s, a); \
 		else                                                                                     \
 			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, U>), dim3(grid), dim3(256), 0, s, a); \

@@ -233,3 +233,33 @@ def test_config4_config5(cfg):
     assert relmax(y, r - torch_part_matvec(m, fe, y, "lower")) < 1e-12
     assert p.level_stats()["syncfree_aborts"] == 0
     p.close()
+
+
+def test_scalar_many_rows_takes_the_wide_chunks():
+    """Scalar matrices of a million rows and more run the row sweeps with 256 rows per workgroup (sweep_geo.hpp);
+    the tuning "gunroll=1" keeps the 128-row form.  Synchronous sweeps are deterministic: every operator gives the
+    same bits in both, and the SpMV is the torch one."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m = W.poisson3d_device(104, 1, dev, grid="uniform")     # 1 124 864 rows
+    assert m["nbrows"] >= 1 << 20
+    n = m["nbrows"]
+    r = W.rhs_vector_device(n, dev)
+    p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
+    p.set_matrix(m)
+    p.ilu0_factorize(2, mode=capi.JACOBI_SYNC)
+    p.jacobi_compute()
+    res = {}
+    try:
+        for k in ("0", "1"):
+            capi.set_tuning("gunroll=" + k)
+            x0 = torch.zeros_like(r)
+            res[k] = [p.spmv(r).clone(), p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC).clone(),
+                      p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC).clone(), p.jacobi_apply(r).clone(),
+                      p.sgs_relax(r, x0, 2, mode=capi.JACOBI_SYNC).clone()]
+    finally:
+        capi.set_tuning("gunroll=0")
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    assert relmax(res["0"][0], torch_part_matvec(m, m["vals"], r, "all")) < 1e-13
+    p.close()
