@@ -45,6 +45,9 @@ def main():
         tune["copies"] = str(rng.choice(["one", "both"]))
         tune["xcdsuper"] = int(rng.choice([1, 4, 16, 64]))
         tune["levelserial"] = int(rng.choice([4096, 4096, 8]))   # 8: the in-order fall-back of the level build
+        tune["levelfast"] = int(rng.choice([1, 1, 0]))           # the polling launch of the level build
+        tune["factorsf"] = str(rng.choice(["0", "1", "1", "2", "3", "p0", "p1"]))  # forms of the exact factorisation
+        tune["factorskip"] = int(rng.integers(0, 2))             # fixed upper blocks left alone by in-place sweeps
         for k, v in tune.items():
             capi.set_tuning("%s=%s" % (k, v))
         if tune["sweepodd"]:
@@ -56,7 +59,14 @@ def main():
                                          "r256,nt1,u2,s1", "r256,nt0,u1,s2", "r128,nt1,u1,s1", "r128,nt1,u1,s1,c1"]))
         capi.set_tuning(tune["sweepw"])
         case = dict(it=it, bs=bs, nb=nb, rowmajor=rm, avg_offdiag=dens, scaling=sc, tune=tune)
-        m = W.random_bsr(nb, bs, avg_offdiag=dens, seed=int(rng.integers(1, 1 << 30)), rowmajor=rm)
+        if rng.integers(0, 4) == 0:
+            # a stencil (short rows: what the plan kernels of the exact factorisation take)
+            g = int(rng.integers(3, 15))
+            m = W.poisson3d(g, bs, rowmajor=rm)
+            nb = m["nbrows"]
+            case.update(stencil=g, nb=nb)
+        else:
+            m = W.random_bsr(nb, bs, avg_offdiag=dens, seed=int(rng.integers(1, 1 << 30)), rowmajor=rm)
         n = nb * bs
         r = rng.uniform(-1, 1, n)
         x0 = rng.uniform(-1, 1, n)
@@ -80,6 +90,10 @@ def main():
             continue
         check("factor_exact", p.get_iluvals(), fe["iluvals"], 1e-9)
         f = p.get_iluvals()
+        # in-place asynchronous sweeps run to convergence reach the same factor (with and without the shortcut)
+        p.ilu0_factorize(p.level_count() + 3, init=init, usescale=sc, mode=capi.ASYNC)
+        check("factor_async", p.get_iluvals(), fe["iluvals"], 1e-8)
+        p.ilu0_factorize(-1, usescale=sc)
         scale = p.get_scale() if sc else None
         # apply: synchronous, exact, asynchronous to convergence
         ainit = int(rng.choice([capi.INIT_A_ZERO, capi.INIT_A_JACOBI]))
@@ -119,7 +133,8 @@ def main():
         p.close()
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
-                 "factor8=1", "gunroll=0", "copies=one", "xcdsuper=16", "levelserial=4096", "r128,nt1,u1,s1"):
+                 "factor8=1", "gunroll=0", "copies=one", "xcdsuper=16", "levelserial=4096", "levelfast=1",
+                 "factorsf=1", "factorsf=p1", "factorskip=1", "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
     for k in sorted(worst):
