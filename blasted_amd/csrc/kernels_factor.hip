@@ -927,8 +927,8 @@ int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s
 			BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 			BHIP_BS_SWITCH(a.pat.bs, a.pat.rowmajor, {
 				if constexpr (FGeo<BS>::SUB >= 16) {
-					// (the plans were laid out for bs == 3 ? 16 : 4 rows per workgroup above; bs = 4 never gets here)
-					static_assert(BS == 4 || FGeo<BS>::RPB == (BS == 3 ? 16 : 4), "rows per workgroup");
+					// (the plans were laid out for bs == 3 ? 16 : 4 rows per workgroup above; bs 1, 2, 4 never get here)
+					static_assert(BS < 3 || BS == 4 || FGeo<BS>::RPB == (BS == 3 ? 16 : 4), "rows per workgroup");
 					hipLaunchKernelGGL((sffplan_fill_kernel<BS, RM>), dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)),
 					                   dim3(256), 0, s, a);
 					hipLaunchKernelGGL((sffplan_kernel<BS, RM>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc,
