@@ -102,7 +102,7 @@ struct LevelSchedule {
 	long nnz_lower = 0, nnz_dupper = 0;
 	// single-launch exact factorisation at bs = 4 (kernels_factor4.hip): longest pair list of a row (-1: not looked
 	// at yet), per-level workgroup layout
-	int f4_maxpairs = -1, f4_grid = 0;
+	int f4_maxpairs = -1, f4_grid = 0, f4_maxtodo = 0;
 	int *f4_desc = nullptr;  // device: the rows' plans, 16 ints per row in padded level order
 };
 

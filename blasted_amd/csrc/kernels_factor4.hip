@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 // register indices).  For stencil-like rows only: at most X4_MAXE entries, X4_MAXL of them lower, X4_MAXP position
 // pairs per row; other patterns take the general kernel.
 // Measured (MI355X, ms per exact factorisation, one launch per level -> general single launch -> this):
-//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 10.1;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.3.
+//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 9.1;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.0.
 // How it got there, at 256^3: first form (indices through the matrix's own arrays, level of a workgroup by binary
 // search) 17.8; per-workgroup table 14.6; row plans 13.3; shape in scalar registers where the four rows agree
 // 13.0; upper blocks without pairs stored by the fill pass instead 11.5; one wait per row with a single polling
-// lane per wave (x4_rows) 10.1.  With nobody waiting (wrong factor, experiment) the launches took 10.4 when the real
+// lane per wave (x4_rows) 10.1; register arrays sized for a 7-point row where the pattern is one 9.1.  With nobody waiting (wrong factor, experiment) the launches took 10.4 when the real
 // ones took 11.5: the rest is the rate at which four waves per SIMD (124 registers, 80 of them operand blocks) turn
 // rows over.  Tried and dropped: a
 // resident grid whose waves walk the units with the next plan requested ahead (15.5 against 14.1 for the form it
@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256) void x4_fill_kernel(const FactorArgs a)
 // scalar registers: which entry is lower, which pair belongs to which entry, where a row ends are then scalar
 // branches instead of 64-bit lane masks and selects (the instruction issue of exactly that bookkeeping is what
 // bounded the first form of this kernel: 11 ms at 256^3 with nobody waiting).  Returns false if the wave gave up.
-template <bool UNI>
+// ME / ML / MP: how many entries that need work, lower entries and position pairs a row may have (the register
+// arrays): 8 / 4 / 8 in general; 4 / 3 / 4 -- a 7-point row -- leaves room for a wave more per SIMD.
+template <bool UNI, int ME, int ML, int MP>
 __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const unsigned w14, const unsigned w15,
                                         const bool ok, const int lane, int *ctl)
 {
@@ -324,23 +326,23 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 	// entries with position pairs; an upper entry without any has been stored by x4_fill_kernel already
 	unsigned pmask = 0u;
 #pragma unroll
-	for (int tt = 0; tt < X4_MAXP; tt++)
+	for (int tt = 0; tt < MP; tt++)
 		pmask |= (tt < np) ? (1u << (X4_CODE(tt) & 7u)) : 0u;
 #define X4_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
 
 	// ---- operands, in operand layout; blocks of other rows may still show the fill pattern
 	// (lane exchanges are kept out of divergent code: a lane that is switched off hands out nothing)
-	double aS[X4_MAXE], uvD[X4_MAXP], dvB[X4_MAXL];
+	double aS[ME], uvD[MP], dvB[ML];
 #pragma unroll
-	for (int q = 0; q < X4_MAXE; q++)
+	for (int q = 0; q < ME; q++)
 		aS[q] = (X4_TODO(q) && ok) ? a.avals[(long)(jbeg + q) * 16 + (q < nl ? offA : offD)] : 0.0;
 #pragma unroll
-	for (int tt = 0; tt < X4_MAXP; tt++) {
+	for (int tt = 0; tt < MP; tt++) {
 		const int up = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
 		uvD[tt] = (tt < np && ok) ? f[(long)up * 16 + offD] : 0.0;
 	}
 #pragma unroll
-	for (int q = 0; q < X4_MAXL; q++) {
+	for (int q = 0; q < ML; q++) {
 		const int dp = __shfl(dw, X4_SLOTLANE(10 + q), 64);
 		dvB[q] = (q < nl && ok) ? f[(long)dp * 16 + offD] : 0.0;
 	}
@@ -348,7 +350,7 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 		const int irow = __shfl(dw, X4_SLOTLANE(1), 64);
 		const int colr = (t < ne && ok) ? a.pat.bcolind[jbeg + t] : 0;
 #pragma unroll
-		for (int q = 0; q < X4_MAXE; q++) {
+		for (int q = 0; q < ME; q++) {
 			const int cq = __shfl(colr, X4_SLOTLANE(q), 64);
 			// (r,c) of this lane's element: D layout (k,m), transposed (m,k)
 			const int r = q < nl ? m : k, c = q < nl ? k : m;
@@ -358,9 +360,9 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 	}
 
 	// ---- the rows' recurrence, entry by entry, the four slots in lockstep
-	double lresA[X4_MAXL];  // finished lower blocks of the row, as element (r = m, c = k): the A-operand layout
+	double lresA[ML];  // finished lower blocks of the row, as element (r = m, c = k): the A-operand layout
 #pragma unroll
-	for (int q = 0; q < X4_MAXL; q++)
+	for (int q = 0; q < ML; q++)
 		lresA[q] = 0.0;
 	// ---- wait until everything the rows of this wave read from other rows has been published.  ONE lane polls, for
 	// the whole wave, the element the first waiting lane misses; when that has arrived everybody re-reads coherently
@@ -370,15 +372,15 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 	int spins = 0;
 	for (;;) {
 		const double *miss = nullptr;
-		int up[X4_MAXP], dp[X4_MAXL];
+		int up[MP], dp[ML];
 #pragma unroll
-		for (int tt = X4_MAXP - 1; tt >= 0; tt--) {
+		for (int tt = MP - 1; tt >= 0; tt--) {
 			up[tt] = __shfl(dw, X4_SLOTLANE(2 + tt), 64);
 			if (tt < np && x4_pending(uvD[tt]))
 				miss = f + (long)up[tt] * 16 + offD;
 		}
 #pragma unroll
-		for (int q = X4_MAXL - 1; q >= 0; q--) {
+		for (int q = ML - 1; q >= 0; q--) {
 			dp[q] = __shfl(dw, X4_SLOTLANE(10 + q), 64);
 			if (q < nl && x4_pending(dvB[q]))
 				miss = f + (long)dp[q] * 16 + offD;
@@ -402,11 +404,11 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 			__builtin_amdgcn_s_sleep(2);
 		}
 #pragma unroll
-		for (int q = 0; q < X4_MAXL; q++)
+		for (int q = 0; q < ML; q++)
 			if (q < nl && x4_pending(dvB[q]))
 				dvB[q] = x4_coherent(f + (long)dp[q] * 16 + offD);
 #pragma unroll
-		for (int tt = 0; tt < X4_MAXP; tt++)
+		for (int tt = 0; tt < MP; tt++)
 			if (tt < np && x4_pending(uvD[tt]))
 				uvD[tt] = x4_coherent(f + (long)up[tt] * 16 + offD);
 		if (++spins > X4_SPIN_LIMIT) {
@@ -418,7 +420,7 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 
 	// ---- the rows' recurrences, entry by entry, the four slots in lockstep, on registers
 #pragma unroll
-	for (int q = 0; q < X4_MAXE; q++) {
+	for (int q = 0; q < ME; q++) {
 		if (!X4_ANY(q < ne))
 			break;
 		const bool valid = X4_TODO(q);
@@ -430,26 +432,26 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 		// (s -= group_gemm(l, u), kernels_factor.hip), so that the factor is the same bits.
 		double res = aS[q];
 #pragma unroll
-		for (int tt = 0; tt < X4_MAXP; tt++) {
+		for (int tt = 0; tt < MP; tt++) {
 			const bool in = X4_PQ(tt) == q;
 			if (!X4_ANY(in))
 				continue;
 			// l_ik: lower entry number pll of this row, finished above, as element (r = m, c = k)
 			const int ll = X4_PLL(tt);
-			const double lA = ll == 0 ? lresA[0] : (ll == 1 ? lresA[1] : (ll == 2 ? lresA[2] : lresA[3]));
+			const double lA = ll == 0 ? lresA[0] : (ll == 1 ? lresA[1] : ((ll == 2 || ML < 4) ? lresA[2] : lresA[ML < 4 ? 2 : 3]));
 			const double lv = (UNI || in) ? lA : 0.0, uv = (UNI || in) ? uvD[tt] : 0.0;
 			res -= mfma444(lowerq ? uv : lv, lowerq ? lv : uv, 0.0);
 		}
-		if (q < X4_MAXL && X4_ANY(valid && lowerq)) {
+		if (q < ML && X4_ANY(valid && lowerq)) {
 			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
 			const bool lw = valid && lowerq;
-			const double prod = mfma444((UNI || lw) ? res : 0.0, (UNI || lw) ? dvB[q < X4_MAXL ? q : 0] : 0.0, 0.0);
+			const double prod = mfma444((UNI || lw) ? res : 0.0, (UNI || lw) ? dvB[q < ML ? q : 0] : 0.0, 0.0);
 			if (lw)
 				res = prod;
 			const double tr = __shfl(res, 16 * m + b4 + k, 64);  // the block transposed inside its slot
-			lresA[q < X4_MAXL ? q : 0] = lw ? tr : 0.0;
+			lresA[q < ML ? q : 0] = lw ? tr : 0.0;
 		}
-		if (q <= X4_MAXL && X4_ANY(diagq)) {
+		if (q <= ML && X4_ANY(diagq)) {
 			const double inv = inverse_b_layout((diagq && ok) ? res : ((k == m) ? 1.0 : 0.0), k, b4, m);
 			if (diagq)
 				res = inv;
@@ -474,6 +476,7 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 // One wave = one unit of four rows of one level; workgroups in level order (that the row with the lowest number
 // among the unfinished ones can always move rests on workgroups being started in the order of their numbers, as
 // for the other single-launch kernels).
+template <int ME, int ML, int MP>
 __global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
 {
 	const int tid = threadIdx.x;
@@ -488,20 +491,30 @@ __global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, cons
 		return;  // (slots fill up in order: an empty first slot is an empty wave)
 	const bool same = (w14 == s14 && w15 == s15) || w14 == 0u;
 	if (__builtin_amdgcn_ballot_w64(!same) == 0ull)
-		(void)x4_rows<true>(a, dw, s14, s15, w14 != 0u, lane, ctl);
+		(void)x4_rows<true, ME, ML, MP>(a, dw, s14, s15, w14 != 0u, lane, ctl);
 	else
-		(void)x4_rows<false>(a, dw, w14, w15, w14 != 0u, lane, ctl);
+		(void)x4_rows<false, ME, ML, MP>(a, dw, w14, w15, w14 != 0u, lane, ctl);
 }
 
 // max over the rows of the number of position pairs of a row
+// out[1]: max over the rows of 1 + the index, inside the row, of the last entry that needs work (the lower ones, the
+// diagonal, upper ones with position pairs)
 __global__ __launch_bounds__(256) void max_pairs_kernel(const Pattern pat, const int *__restrict__ posptr, int *out)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < pat.nbrows)
-		atomicMax(out, posptr[pat.browptr[i + 1]] - posptr[pat.browptr[i]]);
+	if (i >= pat.nbrows)
+		return;
+	const int rp0 = pat.browptr[i], rp1 = pat.browptr[i + 1], dg = pat.diagind[i];
+	atomicMax(out, posptr[rp1] - posptr[rp0]);
+	int last = dg - rp0 + 1;
+	for (int j = dg + 1; j < rp1; j++)
+		if (posptr[j + 1] != posptr[j])
+			last = j - rp0 + 1;
+	atomicMax(out + 1, last);
 }
 
 int g_factor4_enabled = -1;
+int g_x4_small = 1;  // "factor4=s0|s1": the small-array instantiation of the single-launch exact factorisation
 
 }  // namespace
 
@@ -514,15 +527,16 @@ bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream
 		return false;
 	if (ls.f4_maxpairs < 0) {
 		int *d = nullptr;
-		BHIP_CHECK(tracked_malloc(&d, sizeof(int)));
-		BHIP_CHECK(hipMemsetAsync(d, 0, sizeof(int), s));
+		BHIP_CHECK(tracked_malloc(&d, 2 * sizeof(int)));
+		BHIP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), s));
 		hipLaunchKernelGGL(max_pairs_kernel, dim3((unsigned)((a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a.pat,
 		                   a.posptr, d);
-		int h = 0;
-		BHIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s));
+		int h[2] = {0, 0};
+		BHIP_CHECK(hipMemcpyAsync(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
 		BHIP_CHECK(hipStreamSynchronize(s));
 		(void)tracked_free(d);
-		ls.f4_maxpairs = h;
+		ls.f4_maxpairs = h[0];
+		ls.f4_maxtodo = h[1];
 		if (ls.f4_maxpairs <= X4_MAXP) {
 			std::vector<int2> wg;
 			for (int l = 0; l < ls.nlevels; l++)
@@ -560,7 +574,13 @@ int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 		return 0;
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 	hipLaunchKernelGGL(x4_fill_kernel, dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(sffactor4_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc, ls.ctl);
+	// a 7-point-like pattern (at most 3 lower entries, 4 pairs, and nothing to do beyond a row's fourth entry) takes
+	// the instantiation with the small register arrays: 78 instead of 124 registers, a wave or two more per SIMD
+	if (g_x4_small && ls.max_lower <= 3 && ls.f4_maxpairs <= 4 && ls.f4_maxtodo <= 4)
+		hipLaunchKernelGGL((sffactor4_kernel<4, 3, 4>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc, ls.ctl);
+	else
+		hipLaunchKernelGGL((sffactor4_kernel<X4_MAXE, X4_MAXL, X4_MAXP>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
+		                   ls.f4_desc, ls.ctl);
 	BHIP_CHECK(hipGetLastError());
 	int ctl[2] = {0, 0};
 	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
@@ -570,7 +590,10 @@ int launch_factor4_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 
 void set_factor4_enabled(int on)
 {
-	g_factor4_enabled = on;
+	if (on >= 10)
+		g_x4_small = on - 10;
+	else
+		g_factor4_enabled = on;
 }
 
 // returns false when the tuned kernel does not cover the request (caller uses the generic kernel)

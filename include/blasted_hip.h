@@ -230,7 +230,7 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * launch where that is faster (1, default: stencil-like rows of any block size but 2 through the plan kernels --
  * matrix-core at bs = 4, lane-per-row at bs = 1 -- and bs >= 5 in general), always as one launch (2), or always as
  * one launch of the general kernel (3); the factor is the same bits in every form.  "factorsf=p0" keeps the plan
- * kernel of block sizes 3, 5, 7, 8 off.  "levelfast=1" (default) / "levelfast=0": the level-schedule build starts
+ * kernel of block sizes 3, 5, 7, 8 off, "factor4=s0" the small-array instantiation of the bs = 4 one.  "levelfast=1" (default) / "levelfast=0": the level-schedule build starts
  * with one dependency-polling launch (plus a confirming pass) or runs relaxation passes only.  Test hooks:
  * "factorsf=a1" / "levelfast=2" make the single-launch factorisation / the polling launch of the schedule build
  * behave as if a wave had given up waiting, so that the fall-backs run.  "factorskip=1" (default) / "factorskip=0": in-place factorisation sweeps leave
