@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void x1_fill_kernel(const FactorArgs a)
 	}
 }
 
+// ME / ML / MP: entries that need work, lower entries, position pairs a row may have (register arrays): 8 / 4 / 8 in
+// general, 4 / 3 / 4 for a 7-point pattern (as for sffactor4_kernel).
+template <int ME, int ML, int MP>
 __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, const int4 *__restrict__ desc, int *ctl)
 {
 	double *const f = a.out;
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 	// of its pairs, 10..13 diagonal positions of its lower entries' columns, 14 / 15 counts and pair codes
 	const int4 d0 = desc[slot * 4 + 0], d1 = desc[slot * 4 + 1], d2 = desc[slot * 4 + 2], d3 = desc[slot * 4 + 3];
 	const int jbeg = d0.x, irow = d0.y;
-	const int upo[X1_MAXP] = {d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y};
-	const int dpo[X1_MAXL] = {d2.z, d2.w, d3.x, d3.y};
+#define X1_UPO(TT) ((TT) == 0 ? d0.z : (TT) == 1 ? d0.w : (TT) == 2 ? d1.x : (TT) == 3 ? d1.y : (TT) == 4 ? d1.z : (TT) == 5 ? d1.w : (TT) == 6 ? d2.x : d2.y)
+#define X1_DPO(Q) ((Q) == 0 ? d2.z : (Q) == 1 ? d2.w : (Q) == 2 ? d3.x : d3.y)
 	const unsigned w14 = (unsigned)d3.z, w15 = (unsigned)d3.w;
 	const int ne = (int)(w14 & 15u), nl = (int)((w14 >> 4) & 15u), np = (int)((w14 >> 8) & 15u);
 #define X1_CODE(TT) ((TT) < 4 ? (w14 >> (12 + 5 * (TT))) : (w15 >> (5 * ((TT)-4))))
@@ -255,25 +258,25 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 #define X1_PLL(TT) ((int)((X1_CODE(TT) >> 3) & 3u))
 	unsigned pmask = 0u;  // entries with position pairs
 #pragma unroll
-	for (int tt = 0; tt < X1_MAXP; tt++)
+	for (int tt = 0; tt < MP; tt++)
 		pmask |= (tt < np) ? (1u << (X1_CODE(tt) & 7u)) : 0u;
 #define X1_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
 
-	double aS[X1_MAXE], uv[X1_MAXP], dv[X1_MAXL], lres[X1_MAXL];
+	double aS[ME], uv[MP], dv[ML], lres[ML];
 #pragma unroll
-	for (int q = 0; q < X1_MAXE; q++)
+	for (int q = 0; q < ME; q++)
 		aS[q] = X1_TODO(q) ? a.avals[jbeg + q] : 0.0;
 #pragma unroll
-	for (int tt = 0; tt < X1_MAXP; tt++)
-		uv[tt] = (tt < np) ? f[upo[tt]] : 0.0;
+	for (int tt = 0; tt < MP; tt++)
+		uv[tt] = (tt < np) ? f[X1_UPO(tt)] : 0.0;
 #pragma unroll
-	for (int q = 0; q < X1_MAXL; q++) {
-		dv[q] = (q < nl) ? f[dpo[q]] : 1.0;
+	for (int q = 0; q < ML; q++) {
+		dv[q] = (q < nl) ? f[X1_DPO(q)] : 1.0;
 		lres[q] = 0.0;
 	}
 	if (a.scale) {
 #pragma unroll
-		for (int q = 0; q < X1_MAXE; q++)
+		for (int q = 0; q < ME; q++)
 			if (X1_TODO(q)) {
 				aS[q] *= a.scale[irow];
 				aS[q] *= a.scale[a.pat.bcolind[jbeg + q]];
@@ -289,13 +292,13 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 	for (;;) {
 		const double *miss = nullptr;
 #pragma unroll
-		for (int tt = X1_MAXP - 1; tt >= 0; tt--)
+		for (int tt = MP - 1; tt >= 0; tt--)
 			if (tt < np && x1_pending(uv[tt]))
-				miss = f + upo[tt];
+				miss = f + X1_UPO(tt);
 #pragma unroll
-		for (int q = X1_MAXL - 1; q >= 0; q--)
+		for (int q = ML - 1; q >= 0; q--)
 			if (q < nl && x1_pending(dv[q]))
-				miss = f + dpo[q];
+				miss = f + X1_DPO(q);
 		const unsigned long long waiting = __builtin_amdgcn_ballot_w64(miss != nullptr);
 		if (waiting == 0ull)
 			break;
@@ -315,13 +318,13 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 			__builtin_amdgcn_s_sleep(2);
 		}
 #pragma unroll
-		for (int q = 0; q < X1_MAXL; q++)
+		for (int q = 0; q < ML; q++)
 			if (q < nl && x1_pending(dv[q]))
-				dv[q] = x1_coherent(f + dpo[q]);
+				dv[q] = x1_coherent(f + X1_DPO(q));
 #pragma unroll
-		for (int tt = 0; tt < X1_MAXP; tt++)
+		for (int tt = 0; tt < MP; tt++)
 			if (tt < np && x1_pending(uv[tt]))
-				uv[tt] = x1_coherent(f + upo[tt]);
+				uv[tt] = x1_coherent(f + X1_UPO(tt));
 		if (++spins > X1_SPIN_LIMIT) {
 			if ((threadIdx.x & 63) == 0)
 				__hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 
 	// ---- the rows' recurrences, entry by entry in lockstep, on registers
 #pragma unroll
-	for (int q = 0; q < X1_MAXE; q++) {
+	for (int q = 0; q < ME; q++) {
 		if (__builtin_amdgcn_ballot_w64(q < ne) == 0ull)
 			break;
 		const bool valid = X1_TODO(q);
@@ -340,15 +343,15 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 		const bool lowerq = valid && q < nl;
 		double sv = aS[q];
 #pragma unroll
-		for (int tt = 0; tt < X1_MAXP; tt++)
+		for (int tt = 0; tt < MP; tt++)
 			if (X1_PQ(tt) == q) {
 				const int ll = X1_PLL(tt);
-				const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : (ll == 2 ? lres[2] : lres[3]));
+				const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : ((ll == 2 || ML < 4) ? lres[2] : lres[ML < 4 ? 2 : 3]));
 				sv -= lv * uv[tt];
 			}
-		if (q < X1_MAXL && lowerq) {
-			sv = sv / dv[q < X1_MAXL ? q : 0];
-			lres[q < X1_MAXL ? q : 0] = sv;
+		if (q < ML && lowerq) {
+			sv = sv / dv[q < ML ? q : 0];
+			lres[q < ML ? q : 0] = sv;
 		}
 		if (valid) {
 			if (lowerq)
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(256) void sffactor1_kernel(const FactorArgs a, cons
 		}
 	}
 #undef X1_CODE
+#undef X1_UPO
+#undef X1_DPO
 #undef X1_PQ
 #undef X1_PLL
 #undef X1_TODO
@@ -379,8 +384,12 @@ int launch_factor1_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 		return 0;
 	BHIP_CHECK(hipMemsetAsync(ls.ctl, 0, 2 * sizeof(int), s));
 	hipLaunchKernelGGL(x1_fill_kernel, dim3((unsigned)(((long)a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(sffactor1_kernel, dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
-	                   reinterpret_cast<const int4 *>(ls.f4_desc), ls.ctl);
+	if (ls.max_lower <= 3 && ls.f4_maxpairs <= 4 && ls.f4_maxtodo <= 4)
+		hipLaunchKernelGGL((sffactor1_kernel<4, 3, 4>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
+		                   reinterpret_cast<const int4 *>(ls.f4_desc), ls.ctl);
+	else
+		hipLaunchKernelGGL((sffactor1_kernel<X1_MAXE, X1_MAXL, X1_MAXP>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
+		                   reinterpret_cast<const int4 *>(ls.f4_desc), ls.ctl);
 	BHIP_CHECK(hipGetLastError());
 	int ctl[2] = {0, 0};
 	BHIP_CHECK(hipMemcpyAsync(ctl, ls.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
