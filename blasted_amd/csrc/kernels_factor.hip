@@ -723,7 +723,9 @@ __global__ __launch_bounds__(256) void sffplan_fill_kernel(const FactorArgs a)
 	}
 }
 
-template <int BS, bool RM>
+// ME / ML / MP: entries that need work, lower entries, position pairs a row may have (register arrays): 8 / 4 / 8 in
+// general, 4 / 3 / 4 for a 7-point pattern (as for sffactor4_kernel).
+template <int BS, bool RM, int ME, int ML, int MP>
 __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
 {
 	using Ge = FGeo<BS>;
@@ -747,30 +749,30 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 #define XP_PLL(TT) ((int)((XP_CODE(TT) >> 3) & 3u))
 	unsigned pmask = 0u;  // entries with position pairs; an upper entry without any has been stored by the fill pass
 #pragma unroll
-	for (int tt = 0; tt < XP_MAXP; tt++)
+	for (int tt = 0; tt < MP; tt++)
 		pmask |= (tt < np) ? (1u << (XP_CODE(tt) & 7u)) : 0u;
 #define XP_TODO(Q) ((Q) < ne && ((Q) <= nl || ((pmask >> (Q)) & 1u) != 0u))
 
 	// ---- operands; blocks of other rows may still show the fill pattern
-	double aS[XP_MAXE], uv[XP_MAXP], dv[XP_MAXL], lres[XP_MAXL];
-	int upo[XP_MAXP], dpo[XP_MAXL];
+	double aS[ME], uv[MP], dv[ML], lres[ML];
+	int upo[MP], dpo[ML];
 #pragma unroll
-	for (int q = 0; q < XP_MAXE; q++)
+	for (int q = 0; q < ME; q++)
 		aS[q] = (XP_TODO(q) && active) ? a.avals[(long)(jbeg + q) * BS2 + e] : 0.0;
 #pragma unroll
-	for (int tt = 0; tt < XP_MAXP; tt++) {
+	for (int tt = 0; tt < MP; tt++) {
 		upo[tt] = __shfl(dw, gbase + 2 + tt, 64);
 		uv[tt] = (tt < np && active) ? f[(long)upo[tt] * BS2 + e] : 0.0;
 	}
 #pragma unroll
-	for (int q = 0; q < XP_MAXL; q++) {
+	for (int q = 0; q < ML; q++) {
 		dpo[q] = __shfl(dw, gbase + 10 + q, 64);
 		dv[q] = (q < nl && active) ? f[(long)dpo[q] * BS2 + e] : 0.0;
 		lres[q] = 0.0;
 	}
 	if (a.scale) {
 #pragma unroll
-		for (int q = 0; q < XP_MAXE; q++)
+		for (int q = 0; q < ME; q++)
 			if (XP_TODO(q) && active) {
 				const int col = a.pat.bcolind[jbeg + q];
 				aS[q] *= a.scale[(long)irow * BS + r] * a.scale[(long)col * BS + c];
@@ -782,11 +784,11 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 	for (;;) {
 		const double *miss = nullptr;
 #pragma unroll
-		for (int tt = XP_MAXP - 1; tt >= 0; tt--)
+		for (int tt = MP - 1; tt >= 0; tt--)
 			if (tt < np && sff_pending(uv[tt]))
 				miss = f + (long)upo[tt] * BS2 + e;
 #pragma unroll
-		for (int q = XP_MAXL - 1; q >= 0; q--)
+		for (int q = ML - 1; q >= 0; q--)
 			if (q < nl && sff_pending(dv[q]))
 				miss = f + (long)dpo[q] * BS2 + e;
 		const unsigned long long waiting = __builtin_amdgcn_ballot_w64(miss != nullptr);
@@ -812,13 +814,13 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 			__builtin_amdgcn_s_sleep(2);
 		}
 #pragma unroll
-		for (int q = 0; q < XP_MAXL; q++)
+		for (int q = 0; q < ML; q++)
 			if (q < nl && sff_pending(dv[q]))
 				dv[q] = __longlong_as_double((long long)__hip_atomic_load(
 				    reinterpret_cast<const unsigned long long *>(f + (long)dpo[q] * BS2 + e), __ATOMIC_RELAXED,
 				    __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-		for (int tt = 0; tt < XP_MAXP; tt++)
+		for (int tt = 0; tt < MP; tt++)
 			if (tt < np && sff_pending(uv[tt]))
 				uv[tt] = __longlong_as_double((long long)__hip_atomic_load(
 				    reinterpret_cast<const unsigned long long *>(f + (long)upo[tt] * BS2 + e), __ATOMIC_RELAXED,
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 	// ---- the rows' recurrences on registers, entry by entry, the groups of a wave in lockstep (the group
 	// products exchange lanes: no divergence around them)
 #pragma unroll
-	for (int q = 0; q < XP_MAXE; q++) {
+	for (int q = 0; q < ME; q++) {
 		if (__builtin_amdgcn_ballot_w64(q < ne) == 0ull)
 			break;
 		const bool valid = XP_TODO(q);
@@ -841,24 +843,24 @@ __global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const 
 			continue;
 		double sv = aS[q];
 #pragma unroll
-		for (int tt = 0; tt < XP_MAXP; tt++) {
+		for (int tt = 0; tt < MP; tt++) {
 			const bool in = valid && XP_PQ(tt) == q;
 			if (__builtin_amdgcn_ballot_w64(in) == 0ull)
 				continue;
 			const int ll = XP_PLL(tt);
-			const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : (ll == 2 ? lres[2] : lres[3]));
+			const double lv = ll == 0 ? lres[0] : (ll == 1 ? lres[1] : ((ll == 2 || ML < 4) ? lres[2] : lres[ML < 4 ? 2 : 3]));
 			sv -= group_gemm<BS, BSP>(in ? lv : 0.0, in ? uv[tt] : 0.0, gbase, r, c);
 		}
 		const bool lowerq = valid && q < nl, diagq = valid && q == nl;
-		if (q < XP_MAXL && __builtin_amdgcn_ballot_w64(lowerq) != 0ull) {
+		if (q < ML && __builtin_amdgcn_ballot_w64(lowerq) != 0ull) {
 			// S * inverse(U_jj): diagonal blocks are stored inverted as soon as they are final
-			const double prod = group_gemm<BS, BSP>(lowerq ? sv : 0.0, lowerq ? dv[q < XP_MAXL ? q : 0] : 0.0, gbase, r, c);
+			const double prod = group_gemm<BS, BSP>(lowerq ? sv : 0.0, lowerq ? dv[q < ML ? q : 0] : 0.0, gbase, r, c);
 			if (lowerq) {
 				sv = prod;
-				lres[q < XP_MAXL ? q : 0] = prod;
+				lres[q < ML ? q : 0] = prod;
 			}
 		}
-		if (q <= XP_MAXL && __builtin_amdgcn_ballot_w64(diagq) != 0ull) {
+		if (q <= ML && __builtin_amdgcn_ballot_w64(diagq) != 0ull) {
 			const double inv = group_inverse<BS, BSP>(diagq ? sv : ((r == c) ? 1.0 : 0.0), gbase, r, c);
 			if (diagq)
 				sv = inv;
@@ -931,8 +933,12 @@ int launch_factor_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t s
 					static_assert(BS < 3 || BS == 4 || FGeo<BS>::RPB == (BS == 3 ? 16 : 4), "rows per workgroup");
 					hipLaunchKernelGGL((sffplan_fill_kernel<BS, RM>), dim3((unsigned)(((long)a.pat.nbrows + 15) / 16)),
 					                   dim3(256), 0, s, a);
-					hipLaunchKernelGGL((sffplan_kernel<BS, RM>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a, ls.f4_desc,
-					                   ls.ctl);
+					if (ls.max_lower <= 3 && ls.f4_maxpairs <= 4 && ls.f4_maxtodo <= 4)
+						hipLaunchKernelGGL((sffplan_kernel<BS, RM, 4, 3, 4>), dim3((unsigned)ls.f4_grid), dim3(256), 0, s, a,
+						                   ls.f4_desc, ls.ctl);
+					else
+						hipLaunchKernelGGL((sffplan_kernel<BS, RM, XP_MAXE, XP_MAXL, XP_MAXP>), dim3((unsigned)ls.f4_grid),
+						                   dim3(256), 0, s, a, ls.f4_desc, ls.ctl);
 				}
 			})
 			BHIP_CHECK(hipGetLastError());
