@@ -17,7 +17,9 @@
 // (Round 2, tried here after it had paid in the single-launch factorisation kernels: one lane polling one missing
 // entry for the whole wave before everybody re-reads.  A row of a solve misses at most four 8-byte entries, the gate
 // is one more dependent round trip, and the exact apply got slower: 256^3 bs=4 5.76 -> 5.96 ms, 100^3 bs=8 1.39 ->
-// 1.51, 64^3 0.69 -> 0.75.  Not kept.)
+// 1.51, 64^3 0.69 -> 0.75.  Not kept.  Nor an instantiation of the bs = 4 lower solve with three straight-line
+// passes instead of four for 7-point patterns -- 58-64 registers, eight waves per SIMD instead of seven: 5.62 against
+// 5.62 ms; nor eight waves by a register bound (spills: 5.9 ms).)
 #include "ctx.hpp"
 #include "lanes.hpp"
 
