@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 // register indices).  For stencil-like rows only: at most X4_MAXE entries, X4_MAXL of them lower, X4_MAXP position
 // pairs per row; other patterns take the general kernel.
 // Measured (MI355X, ms per exact factorisation, one launch per level -> general single launch -> this):
-//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 9.1;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 2.0.
+//   256^3 bs=4 (766 levels) 20.1 -> 18.5 -> 8.6;  128^3 bs=4 (382 levels) 5.9 -> 5.9 -> 1.95.
 // How it got there, at 256^3: first form (indices through the matrix's own arrays, level of a workgroup by binary
 // search) 17.8; per-workgroup table 14.6; row plans 13.3; shape in scalar registers where the four rows agree
 // 13.0; upper blocks without pairs stored by the fill pass instead 11.5; one wait per row with a single polling
-// lane per wave (x4_rows) 10.1; register arrays sized for a 7-point row where the pattern is one 9.1.  With nobody waiting (wrong factor, experiment) the launches took 10.4 when the real
+// lane per wave (x4_rows) 10.1; register arrays sized for a 7-point row where the pattern is one 9.1, at six waves 8.6.  With nobody waiting (wrong factor, experiment) the launches took 10.4 when the real
 // ones took 11.5: the rest is the rate at which four waves per SIMD (124 registers, 80 of them operand blocks) turn
 // rows over.  Tried and dropped: a
 // resident grid whose waves walk the units with the next plan requested ahead (15.5 against 14.1 for the form it
@@ -476,8 +476,10 @@ __device__ __forceinline__ bool x4_rows(const FactorArgs &a, const int dw, const
 // One wave = one unit of four rows of one level; workgroups in level order (that the row with the lowest number
 // among the unfinished ones can always move rests on workgroups being started in the order of their numbers, as
 // for the other single-launch kernels).
+// (the occupancy bound of the small instantiation only keeps two stray accumulator registers out of the count:
+// 78 + 2 registers are five waves per SIMD, 78 are six)
 template <int ME, int ML, int MP>
-__global__ __launch_bounds__(256) void sffactor4_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
+__global__ __launch_bounds__(256, ME == 4 ? 6 : 1) void sffactor4_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
 {
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
