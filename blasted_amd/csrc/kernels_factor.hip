@@ -725,8 +725,9 @@ __global__ __launch_bounds__(256) void sffplan_fill_kernel(const FactorArgs a)
 
 // ME / ML / MP: entries that need work, lower entries, position pairs a row may have (register arrays): 8 / 4 / 8 in
 // general, 4 / 3 / 4 for a 7-point pattern (as for sffactor4_kernel).
+// (occupancy bounds of the 7-point instantiation: bs = 5 fits eight waves per SIMD with one register less, 64)
 template <int BS, bool RM, int ME, int ML, int MP>
-__global__ __launch_bounds__(256) void sffplan_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
+__global__ __launch_bounds__(256, (ME == 4 && BS == 5) ? 8 : 1) void sffplan_kernel(const FactorArgs a, const int *__restrict__ desc, int *ctl)
 {
 	using Ge = FGeo<BS>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, BS2 = BS * BS;
