@@ -1,6 +1,6 @@
 // testsolve.cpp -- native (no PETSc) end-to-end driver through the C++ operator API, the counterpart
 // of the reference's tests/testsolve.cpp + tests/solvers.cpp: read a Matrix-Market system, build the
-// preconditioner through SRFactory, solve with BiCGSTAB / Richardson whose matrix-vector products and
+// preconditioner through SRFactory, solve with BiCGSTAB / Richardson / GCR whose matrix-vector products and
 // preconditioner applications run on the GPU, and compare with the known solution.
 // Same command-line option names as the reference driver (tests/testsolve.cpp:133-187).
 #undef NDEBUG
@@ -26,7 +26,7 @@ struct Params {
 	std::string solvertype = "bcgs", precontype = "jacobi", factinittype = "init_original",
 	            applyinittype = "init_zero", mattype = "csr", storageorder = "colmajor", mat_file, b_file,
 	            x_file = "NONE";
-	int blocksize = 4, maxiter = 1000, nbuildsweeps = 1, napplysweeps = 1, threadchunksize = 256;
+	int blocksize = 4, maxiter = 1000, nbuildsweeps = 1, napplysweeps = 1, threadchunksize = 256, restart = 30;
 	double testtol = 1e-4, tol = 1e-6;
 };
 
@@ -50,7 +50,7 @@ static Params parse(int argc, char **argv)
 	S("mat_type", p.mattype); S("storage_order", p.storageorder);
 	S("mat_file", p.mat_file); S("b_file", p.b_file); S("x_file", p.x_file);
 	I("block_size", p.blocksize); I("max_iter", p.maxiter); I("build_sweeps", p.nbuildsweeps);
-	I("apply_sweeps", p.napplysweeps); I("thread_chunk_size", p.threadchunksize);
+	I("apply_sweeps", p.napplysweeps); I("thread_chunk_size", p.threadchunksize); I("solver_restart", p.restart);
 	D("test_tol", p.testtol); D("solver_tol", p.tol);
 	return p;
 }
@@ -147,6 +147,47 @@ static SolveInfo richardson(const SRMatrixView<double, int> &A, const Preconditi
 	return {step, rel};
 }
 
+// right-preconditioned restarted GCR, the reference's flexible test solver (tests/solvers.cpp:247-352): the
+// direction p_k = M r_k is kept beside q_k = A p_k, so M may differ from one application to the next
+static SolveInfo gcr(const SRMatrixView<double, int> &A, const Preconditioner<double, int> &M,
+                     const std::vector<double> &rhs, std::vector<double> &x, double tol, int maxiter, int nrestart)
+{
+	const size_t n = rhs.size();
+	std::vector<double> res(n), z(n), beta(nrestart + 1), qq(nrestart);
+	std::vector<std::vector<double>> p(nrestart, std::vector<double>(n)), q(nrestart, std::vector<double>(n));
+	const double bnorm = std::sqrt(dot(rhs, rhs));
+	double rel = 1.0;
+	int step = 0;
+	while (step < maxiter) {
+		A.gemv3(-1.0, x.data(), 1.0, rhs.data(), res.data());
+		M.apply(res.data(), p[0].data());
+		A.apply(p[0].data(), q[0].data());
+		qq[0] = dot(q[0], q[0]);
+		for (int k = 0; k < nrestart; k++) {
+			const double alpha = dot(res, q[k]) / qq[k];
+			for (size_t i = 0; i < n; i++) {
+				x[i] += alpha * p[k][i];
+				res[i] -= alpha * q[k][i];
+			}
+			rel = std::sqrt(dot(res, res)) / bnorm;
+			step++;
+			if (rel < tol || k == nrestart - 1 || step >= maxiter) break;
+			M.apply(res.data(), z.data());
+			A.apply(z.data(), q[k + 1].data());
+			p[k + 1] = z;
+			for (int i = 0; i <= k; i++) beta[i] = -dot(q[k + 1], q[i]) / qq[i];
+			for (int l = 0; l <= k; l++)
+				for (size_t i = 0; i < n; i++) {
+					p[k + 1][i] += beta[l] * p[l][i];
+					q[k + 1][i] += beta[l] * q[l][i];
+				}
+			qq[k + 1] = dot(q[k + 1], q[k + 1]);
+		}
+		if (rel < tol) break;
+	}
+	return {step, rel};
+}
+
 template <int bs>
 static int test_solve(const Params &params)
 {
@@ -185,6 +226,8 @@ static int test_solve(const Params &params)
 		info = richardson(*mat, *prec, b, x, params.tol, params.maxiter);
 	else if (params.solvertype == "bcgs")
 		info = bicgstab(*mat, *prec, b, x, params.tol, params.maxiter);
+	else if (params.solvertype == "gcr")
+		info = gcr(*mat, *prec, b, x, params.tol, params.maxiter, params.restart);
 	else {
 		std::cerr << " ! Invalid solver option!\n";
 		std::abort();

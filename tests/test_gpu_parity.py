@@ -330,8 +330,58 @@ def test_ilu_factor_async_converges_to_exact(golden, case):
     p.close()
 
 
+ZERO_INIT_CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "poisson16_bs4", "poisson11_bs4_row", "poisson12_bs5",
+                   "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4"]
+
+
+@pytest.mark.parametrize("case", ZERO_INIT_CASES)
+@pytest.mark.parametrize("factorskip", ["1", "0"])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_block_zero_init_factorisation_converges_to_exact(golden, case, factorskip, usescale):
+    """INIT_F_ZERO for the BLOCK factorisation (src/async_blockilu_factor.cpp:65-69), the initial guess of the
+    reference's own native cases (tests/CMakeLists.txt:104-111, 157-173: BSR4ILU0{Row,Col}major,
+    ThreadedBSR4ILU0Colmajor, all `--fact_init_type init_zero`).  From a zero factor the first in-place sweeps
+    invert diagonal blocks that are still zero: the lower blocks that depend on them are NaN / inf until the
+    rows they read are final, and then they are recomputed from the matrix block -- nothing non-finite may
+    survive (neither through the adjugate inverse, nor the MFMA accumulation, nor the fixed-upper-block
+    shortcut, which may only skip a block once a sweep has stored it).  After max(90, 2 x levels + 2) sweeps the
+    factor is the exact one to 1e-10, with and without the shortcut, and the two agree bit for bit on the blocks
+    the shortcut leaves alone."""
+    if usescale and case.startswith("random"):
+        pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
+    m = matrices(golden)[case]()
+    bs2 = m["bs"] ** 2
+    nlev = int(W.dependency_levels(m).max()) + 1
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ZERO, usescale=usescale, compute_info=True)
+    # the serial sweep does not depend on the initial guess (every entry it reads it has already written)
+    assert np.array_equal(exact["iluvals"], O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=usescale)["iluvals"])
+    p = make_prec(m)
+    capi.set_tuning("factorskip=" + factorskip)
+    try:
+        info = p.ilu0_factorize(max(90, 2 * nlev + 2), init=capi.INIT_F_ZERO, usescale=usescale, mode=capi.ASYNC, compute_info=True)
+        got = p.get_iluvals()
+        assert np.all(np.isfinite(got))
+        assert rel(got, exact["iluvals"]) < TOL_EXACT
+        # PrecInfo: the initial remainder of a zero factor is ||A|| (scaled), the final one vanishes
+        assert info[1] > 0 and info[0] / info[1] < 1e-12
+        assert rel(info[1:2], exact["precinfo"][1:2]) < 1e-12
+        # a few sweeps only (the reference's threaded case builds with 10): finite wherever the oracle's
+        # synchronous model of the same sweeps is, i.e. the non-finite entries of early sweeps do not spread
+        p.ilu0_factorize(3, init=capi.INIT_F_ZERO, usescale=usescale, mode=capi.JACOBI_SYNC)
+        g3 = p.get_iluvals().reshape(-1, bs2)
+        w3 = O.ilu0_factorize(m, None, 3, mode=O.JACOBI_SYNC, init=O.INIT_F_ZERO, usescale=usescale)["iluvals"].reshape(-1, bs2)
+        # (diagonal blocks are stored inverted at the end: a block with one bad entry is bad as a whole)
+        fin_w = np.isfinite(w3).all(axis=1)
+        fin_g = np.isfinite(g3).all(axis=1)
+        assert np.array_equal(fin_w, fin_g)
+        assert fin_w.any() and rel(g3[fin_w], w3[fin_w]) < TOL_SYNC
+    finally:
+        capi.set_tuning("factorskip=1")
+    p.close()
+
+
 @pytest.mark.parametrize("case", ["poisson16_bs4", "2dcyl1_bs4_col", "poisson9_bs8", "poisson12_bs5", "poisson16_csr"])
-@pytest.mark.parametrize("init", [capi.INIT_F_ORIGINAL, capi.INIT_F_SGS])
+@pytest.mark.parametrize("init", [capi.INIT_F_ORIGINAL, capi.INIT_F_SGS, capi.INIT_F_ZERO])
 @pytest.mark.parametrize("usescale", [False, True])
 def test_factor_sweeps_leave_fixed_upper_blocks_alone(golden, case, init, usescale):
     """In-place factorisation sweeps after the first neither read nor write an upper block without position pairs
@@ -693,6 +743,36 @@ def test_medium_poisson_64_against_oracle():
     exact = O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL)
     za = p.ilu0_apply(r, 3, mode=capi.ASYNC)
     assert np.abs(za - exact).max() <= np.abs(z - exact).max() * 1.0001
+    p.close()
+
+
+@pytest.mark.parametrize("interleave", ["0", "1"])
+def test_async_sweeps_are_never_worse_than_synchronous_ones_64(interleave):
+    """SURVEY 8(d) tier P4 as a gate: on Poisson 64^3 bs=4 (the bench generator) the distance of the HIP ASYNC
+    application to the exact triangular solves after s+s sweeps, s in {1, 3, 5}, is at most that of the oracle's
+    synchronous Jacobi sweeps at the same count (a chaotic in-place sweep sees at least what the previous sweep
+    left), in 2-norm and for the intermediate y as well; and it decreases with s.  Both row orders of the sweep."""
+    m = W.poisson3d(66, 4, grid="uniform")
+    r = W.rhs_vector(m["nbrows"] * 4)
+    fe = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    ze = O.ilu0_apply(m, fe, r, 1, mode=O.GS_SERIAL)
+    p = make_prec(m)
+    p.ilu0_factorize(-1)
+    capi.set_tuning("interleave=" + interleave)
+    try:
+        last = np.inf
+        for s in (1, 3, 5):
+            zs = O.ilu0_apply(m, fe, r, s, mode=O.JACOBI_SYNC)
+            es = np.linalg.norm(zs - ze) / np.linalg.norm(ze)
+            worst = 0.0
+            for _ in range(3):   # chaotic: not the same result twice
+                za = p.ilu0_apply(r, s, mode=capi.ASYNC)
+                worst = max(worst, np.linalg.norm(za - ze) / np.linalg.norm(ze))
+            assert worst <= es * (1 + 1e-9), (s, worst, es)
+            assert worst < last
+            last = worst
+    finally:
+        capi.set_tuning("interleave=0")
     p.close()
 
 

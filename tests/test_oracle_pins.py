@@ -15,7 +15,7 @@ import pytest
 
 import oracle as O
 from blasted_amd import mtxio, workloads as W
-from krylov import bicgstab
+from krylov import bicgstab, gcr
 
 DBL_EPS = np.finfo(np.float64).eps
 
@@ -320,7 +320,7 @@ def test_solve_known_answer(golden, name, mat, bs, rowmajor, prec, tol, testtol,
         P = lambda v: O.sgs_apply(m, d, v, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
     else:
         # fact_init_type init_zero, 1 build sweep, 1 apply sweep at OMP_NUM_THREADS=1
-        init = O.INIT_F_ZERO if bs == 1 else O.INIT_F_ORIGINAL
+        init = O.INIT_F_ZERO
         f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=init)["iluvals"]
         P = lambda v: O.ilu0_apply(m, f, v, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)
     # the reference's own parameters must converge within its max_iter ...
@@ -335,14 +335,52 @@ def test_solve_known_answer(golden, name, mat, bs, rowmajor, prec, tol, testtol,
     assert np.linalg.norm(x - xk) < max(testtol, floor)
 
 
+def test_gcr_none_colmajor(golden):
+    """BSR4GCRNoneColmajor, tests/CMakeLists.txt:122-129: the reference's flexible solver (tests/solvers.cpp:247-352),
+    --solver_tol 1e-12 --test_tol 1e-8 --max_iter 1500 --solver_restart 200, no preconditioner."""
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False)
+    b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
+    xk = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
+    x, its, rel = gcr(lambda v: O.spmv(m, v), lambda v: v.copy(), b, 1e-12, 1500, restart=200)
+    assert rel < 1e-12 and its <= 1500
+    assert np.linalg.norm(x - xk) < 1e-8
+
+
+def test_gcr_takes_a_preconditioner_that_changes(golden):
+    """What GCR is in the reference for: a preconditioner that is a different operator at every application
+    (the threaded asynchronous sweeps).  Here: serial ILU(0) applications whose sweep count alternates between
+    calls and a factor-of-(1 +- 0.3) scaling that changes every call -- BiCGSTAB's recurrences assume one
+    fixed M, GCR keeps M's actual output as its direction and converges regardless."""
+    m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False)
+    b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
+    xk = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    calls = [0]
+
+    def P(v):
+        calls[0] += 1
+        k = calls[0]
+        z = O.ilu0_apply(m, f, v, 1 + k % 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)
+        return z * (1.0 + 0.3 * np.sin(1.7 * k))
+    x, its, rel = gcr(lambda v: O.spmv(m, v), P, b, 1e-12, 600, restart=30)
+    assert rel < 1e-12
+    assert np.linalg.norm(x - xk) < 1e-8
+
+
 def test_threaded_bsr4_ilu0_colmajor(golden):
     """ThreadedBSR4ILU0Colmajor, tests/CMakeLists.txt:165-173: init_zero, 10 build / 15 apply sweeps."""
     m = mtxio.read_mtx_bsr(G(golden, "2dcyl1.mtx"), 4, False)
     b = mtxio.read_mtx_dense(G(golden, "2dcyl1_b.mtx"))
     xk = mtxio.read_mtx_dense(G(golden, "2dcyl1_x.mtx"))
-    # zero init for the block factorisation gives singular U_jj on the first sweep in a synchronous
-    # model; the reference test runs it threaded where it behaves as Gauss-Seidel.  Use the threaded mode.
-    f = O.ilu0_factorize(m, None, 10, mode=O.ASYNC_OMP, init=O.INIT_F_ORIGINAL, chunk=256)["iluvals"]
+    # From a zero factor the first sweep inverts diagonal blocks another thread may not have written yet
+    # (0 * inf = NaN in the lower blocks that read them); every later sweep recomputes such a block from the
+    # matrix block, so nothing non-finite survives once the rows it reads are done -- the reference's case
+    # relies on exactly that.  The restatement's inverse takes a zero block without trapping.
+    f = O.ilu0_factorize(m, None, 10, mode=O.ASYNC_OMP, init=O.INIT_F_ZERO, chunk=256)["iluvals"]
+    assert np.all(np.isfinite(f))
+    # 10 threaded in-place sweeps over 446 block-rows (2 chunks) are past the fixed point: the serial factor
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, init=O.INIT_F_ZERO)["iluvals"]
+    assert np.abs(f - exact).max() <= 1e-10 * np.abs(exact).max()
     P = lambda v: O.ilu0_apply(m, f, v, 15, mode=O.ASYNC_OMP, init=O.INIT_A_ZERO, chunk=256)
     x, its, rel = bicgstab(lambda v: O.spmv(m, v), P, b, 1e-10, 200)
     assert rel < 1e-10 and its <= 200

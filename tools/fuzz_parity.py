@@ -78,11 +78,19 @@ def main():
         check("spmv", p.spmv(r), O.spmv(m, r), 1e-12)
         check("gemv3", p.gemv3(0.7, r, -1.3, x0), O.gemv3(m, 0.7, r, -1.3, x0), 1e-12)
         # factorisation: synchronous sweeps and the exact form
-        init = int(rng.choice([capi.INIT_F_ORIGINAL, capi.INIT_F_SGS]))
+        # (INIT_F_ZERO: the reference's own native block cases start from it, tests/CMakeLists.txt:104-111,157-173;
+        # its first synchronous sweeps invert zero diagonal blocks -- compare where the oracle's model is finite)
+        init = int(rng.choice([capi.INIT_F_ORIGINAL, capi.INIT_F_SGS, capi.INIT_F_ZERO]))
         p.ilu0_factorize(2, init=init, usescale=sc, mode=capi.JACOBI_SYNC)
         want = O.ilu0_factorize(m, pos, 2, mode=O.JACOBI_SYNC, init=init, usescale=sc)
         if np.all(np.isfinite(want["iluvals"])) and np.abs(want["iluvals"]).max() < 1e8:
             check("factor_sync", p.get_iluvals(), want["iluvals"], 1e-10)
+        elif init == capi.INIT_F_ZERO:
+            wb, gb = want["iluvals"].reshape(-1, bs * bs), p.get_iluvals().reshape(-1, bs * bs)
+            fin = np.isfinite(wb).all(axis=1)
+            assert np.array_equal(fin, np.isfinite(gb).all(axis=1)), dict(case, what="factor_sync_zero finite blocks")
+            if fin.any() and np.abs(wb[fin]).max() < 1e8:
+                check("factor_sync_zero", gb[fin], wb[fin], 1e-10)
         p.ilu0_factorize(-1, usescale=sc)
         fe = O.ilu0_factorize(m, pos, 1, mode=O.GS_SERIAL, usescale=sc)
         if not (np.all(np.isfinite(fe["iluvals"])) and np.abs(fe["iluvals"]).max() < 1e8):
