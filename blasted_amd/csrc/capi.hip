@@ -215,15 +215,12 @@ struct PinTable {
 	std::mutex mu;
 	std::map<uintptr_t, size_t> ranges;
 	long registered_bytes = 0;
-
-	~PinTable()
-	{
-		for (auto &kv : ranges)
-			(void)hipHostUnregister(reinterpret_cast<void *>(kv.first));
-	}
 };
 
-PinTable g_pins;
+// Never destroyed: a static destructor would run at process exit in an order that is undefined with respect to
+// the HIP runtime's own teardown, and must not call into it (hipHostUnregister after the runtime is gone).  Ranges
+// still registered at exit are the caller's to release (blasted_hip_host_unregister); the OS unlocks the pages.
+PinTable &g_pins = *new PinTable;
 
 }  // namespace
 

@@ -40,13 +40,13 @@ struct LocalMatrix {
 	std::vector<PetscInt> ia, ja, diag;
 	Mat A = NULL;
 	const PetscScalar *vals = NULL;
-	// -blasted_pin_host_arrays: host ranges this operator page-locked (the value array, the vectors it was
-	// applied to), released with the operator
+	// -blasted_pin_host_arrays: host ranges this operator page-locked (the Mat's value array), released with
+	// the operator
 	bool pin = false;
 	std::vector<const void *> pinned;
 	void pin_range(const void *p, const size_t nbytes)
 	{
-		if (!pin || !p || nbytes < (1u << 20) || pinned.size() >= 8)
+		if (!pin || !p || nbytes < (1u << 16) || pinned.size() >= 8)
 			return;
 		for (const void *q : pinned)
 			if (q == p)
@@ -367,9 +367,12 @@ PetscErrorCode create_operator(PC pc)
 	}
 	ctx->bprec = reinterpret_cast<void *>(precop);
 	register_local_matrix(ctx->bprec, lm);  // released in cleanup_blasted together with the operator
-	// Not a reference option: page-lock the Mat's value array and the vectors the operator is applied to, so
-	// that the host-vector path copies by direct DMA.  Only for applications that keep these arrays alive
-	// until the PC is destroyed (PETSc's Mat and KSP work vectors are); off by default.
+	// Not a reference option: page-lock the Mat's value array, so that every compute() uploads it by direct DMA.
+	// The Mat is the caller's and outlives the PC (KSPDestroy -> PCDestroy -> cleanup_blasted comes before the
+	// application's MatDestroy).  Vectors are NOT pinned: the vectors a PC is applied to are KSP work vectors, and
+	// KSPDestroy resets the KSP -- freeing them -- BEFORE it destroys the PC, so a range registered for the
+	// operator's lifetime would be freed while registered (the stale-range hazard described in blasted_hip.h).
+	// Device-resident vectors (VecHIP) are the way around the vector transfers.  Off by default.
 	{
 		PetscBool set = PETSC_FALSE, val = PETSC_FALSE;
 		PetscOptionsGetBool(NULL, NULL, "-blasted_pin_host_arrays", &val, &set);
@@ -509,11 +512,6 @@ PetscErrorCode apply_local_blasted(PC pc, Vec r, Vec z)
 	PetscReal *za;
 	ierr = VecGetArray(z, &za); CHKERRQ(ierr);
 	ierr = VecGetArrayRead(r, &ra); CHKERRQ(ierr);
-	if (LocalMatrix *lm = local_matrix_of(ctx->bprec)) {
-		const size_t nbytes = sizeof(PetscReal) * (size_t)prec->dim();
-		lm->pin_range(ra, nbytes);
-		lm->pin_range(za, nbytes);
-	}
 	{
 		const StopWatch sw;
 		prec->apply(ra, za);  // host vectors: r H2D, sweeps, z D2H

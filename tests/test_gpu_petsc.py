@@ -41,15 +41,8 @@ def run(tmp_path, petsc_opts, mat_type="baij", vec_type="seq", pc=("bjacobi", "s
         e.pop(k, None)
     e.update(env or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e)
-    if r.returncode == -6 and expect_rc == 0 and "outstanding_accesses = 0\ndone = 1" in r.stdout:
-        # seen once in ~150 runs (round 2): glibc "double free or corruption" abort AFTER the driver had finished
-        # and torn everything down, i.e. while the process's static destructors / the HIP runtime's exit
-        # handlers ran.  Not reproducible under MALLOC_CHECK_=3 MALLOC_PERTURB_ nor with an ASan build of the host
-        # side; the report is line-buffered so that the place shows.  The results are complete: go on, loudly.
-        import warnings
-        warnings.warn("petsc_driver aborted during process teardown after a complete run: " + r.stderr[-300:])
-    else:
-        assert r.returncode == expect_rc, r.stdout[-2000:] + r.stderr[-2000:]
+    # (the driver's report is line-buffered: if the process ever dies, what it printed shows how far it got)
+    assert r.returncode == expect_rc, r.stdout[-3000:] + r.stderr[-2000:]
     rep = {}
     for line in r.stdout.splitlines():
         if " = " in line:
@@ -107,6 +100,17 @@ def test_pcshell_ilu0_matches_oracle(tmp_path, mat_type, vec_type):
         assert int(rep["hip_vector_accesses"]) >= 4   # r and z of two applies went through VecHIPGetArray...
     else:
         assert rep["hip_vector_accesses"] == "0"
+
+
+def test_pcshell_pinned_value_array(tmp_path):
+    """-blasted_pin_host_arrays (not a reference option): the Mat's value array is page-locked for the operator's
+    lifetime and released with it (cleanup_blasted); results are the same bits as without, through the set-up on
+    changed values too."""
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
+    _, plain, _ = run(tmp_path, opts, env=SYNC)
+    rep, pinned, _ = run(tmp_path, opts + ["-blasted_pin_host_arrays", "1"], env=SYNC)
+    check_common(rep, pinned, 4, homogeneous=False)
+    assert np.array_equal(plain["z"], pinned["z"]) and np.array_equal(plain["z2"], pinned["z2"])
 
 
 def test_pcshell_ilu0_scaled_with_info(tmp_path):

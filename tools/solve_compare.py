@@ -85,6 +85,10 @@ def gcr(A, M, b, tol=1e-8, maxit=1200, restart=30):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 160
     bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    only = [a[5:] for a in sys.argv[3:] if a.startswith("only=")]
+    solver = ([a[7:] for a in sys.argv[3:] if a.startswith("solver=")] or ["bcgs"])[-1]
+    restart = int(([a[8:] for a in sys.argv[3:] if a.startswith("restart=")] or ["30"])[-1])
+    specs = [a for a in sys.argv[3:] if not a.startswith(("only=", "solver=", "restart="))]
     dev = torch.device("cuda", 0)
     # Kronecker product (scalar 7-point Poisson) x (one fixed, slightly non-symmetric bs x bs block with
     # positive spectrum): a well-posed system.  (The slot-dependent inflation of workloads.poisson3d, made to
@@ -116,10 +120,6 @@ def main():
         ("sapilu0: async 3 build, exact apply", lambda: p.ilu0_factorize(3), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
         ("seqilu0: exact build, exact apply", lambda: p.ilu0_factorize(-1), lambda v: p.ilu0_apply(v, 1, mode=capi.LEVEL)),
     ]
-    only = [a[5:] for a in sys.argv[3:] if a.startswith("only=")]
-    solver = ([a[7:] for a in sys.argv[3:] if a.startswith("solver=")] or ["bcgs"])[-1]
-    restart = int(([a[8:] for a in sys.argv[3:] if a.startswith("restart=")] or ["30"])[-1])
-    specs = [a for a in sys.argv[3:] if not a.startswith(("only=", "solver=", "restart="))]
     if only:
         variants = [v for v in variants if any(o in v[0] for o in only)]
     for spec in specs:
