@@ -51,7 +51,7 @@ CONFIGS = {
 }
 
 
-def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs):
+def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed=0):
     """compulsory bytes, every array touched once per sweep, from the pattern's counts."""
     B, S, I = 8 * bs * bs, 8 * bs, 4
     lower = nnzl * (B + I) + 2 * nb * I + 3 * nb * S
@@ -61,9 +61,14 @@ def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs):
         "sgs_pair": (nnzl + nnzu) * (B + I) + 2 * nb * B + 4 * nb * I + 6 * nb * S,
         "sgs_bwd": nnzu * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
         "sgs_relax_pass": (nnzl + nnzu) * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
+        "sgs_fwd": nnzl * (B + I) + nb * B + 2 * nb * I + 3 * nb * S,
         "factor_sweep": 3 * nnzb * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
+        # what an in-place sweep TOUCHES once the upper blocks without position pairs hold their value (all sweeps
+        # after INIT_F_ORIGINAL, tuning factorskip=1): their matrix block is not read, their factor block neither
+        # read nor written; every index array is still walked
+        "factor_sweep_touched": 3 * (nnzb - nfixed) * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
         "spmv": nnzb * (B + I) + (nb + 1) * I + 2 * nb * S,
-        "nbrows": nb, "nnzb": nnzb, "nnzl": nnzl, "nnzu": nnzu, "pairs": npairs,
+        "nbrows": nb, "nnzb": nnzb, "nnzl": nnzl, "nnzu": nnzu, "pairs": npairs, "fixed_upper": nfixed,
     }
 
 
@@ -72,7 +77,8 @@ def algorithmic_bytes(n, bs):
     nb = n ** 3
     nnzb = 7 * n ** 3 - 6 * n ** 2
     nnzl = 3 * n ** 3 - 3 * n ** 2
-    return pattern_bytes(nb, nnzb, nnzl, nnzl, nnzl, bs)
+    # (a 7-point row's three upper blocks have no position pairs: only diagonal blocks do)
+    return pattern_bytes(nb, nnzb, nnzl, nnzl, nnzl, bs, nfixed=nnzl)
 
 
 def matrix_counts(m):
@@ -86,7 +92,9 @@ def matrix_counts(m):
 def unit_of(op, ab):
     """(bytes of one unit of `value`, bytes of one launch of the dominant kernel, which timing bucket it is in)"""
     return {"ilu_apply": (ab["ilu_pair"], ab["upper_sweep"], "upper"),
-            "sgs_apply": (ab["sgs_pair"], ab["sgs_bwd"], "upper"),
+            # (ASYNC-mode SGS application = ONE exact forward pass + s backward sweeps: the unit is a backward sweep,
+            # the forward pass is accounted per step in main())
+            "sgs_apply": (ab["sgs_bwd"], ab["sgs_bwd"], "upper"),
             "sgs_relax": (2 * ab["sgs_relax_pass"], ab["sgs_relax_pass"], "upper"),
             "spmv": (ab["spmv"], ab["spmv"], "lower"),
             "factor": (ab["factor_sweep"], ab["factor_sweep"], "lower")}[op]
@@ -229,6 +237,109 @@ def quality_figures(p, capi, torch, r, z, s):
     return out
 
 
+def fixed_upper_blocks(p, m, gen):
+    """Upper blocks without position pairs (what factorskip leaves alone).  A 7-point row: all its upper blocks."""
+    nb, nnzb, nnzl, nnzu = matrix_counts(m)
+    if gen != "unstructured":
+        return nnzu
+    import numpy as np
+    posptr = p.ilu0_positions()[0]
+    rp = m["browptr"].cpu().numpy().astype(np.int64)
+    col = m["bcolind"].cpu().numpy()
+    rowof = np.repeat(np.arange(nb, dtype=np.int64), rp[1:] - rp[:-1])
+    return int(((col > rowof) & (posptr[1:] == posptr[:-1])).sum())
+
+
+def short_run(k, dev, stream, capi, workloads, torch, steps=5, warmup=2, reuse=None):
+    """A short measurement of BASELINE configuration k for the default run's `other_configs` block: the same
+    timed-region protocol as main() (operator applied `steps` times after `warmup`, HIP events of the library
+    around every sweep inside the region), reduced to value / kernel time / roofline fraction."""
+    cfg = CONFIGS[k]
+    n, bs, s, op = cfg["n"], cfg["bs"], cfg["sweeps"], cfg["op"]
+    t_setup = time.perf_counter()
+    if reuse is not None:
+        p, m, r, z = reuse
+    else:
+        if cfg["gen"] == "unstructured":
+            m = workloads.unstructured_bsr(n, bs, device=dev)
+        else:
+            m = workloads.poisson3d_device(n, bs, dev, grid=cfg["grid"])
+        r = workloads.rhs_vector_device(m["nbrows"] * bs, dev)
+        z = torch.zeros_like(r)
+        p = capi.Prec(dev.index or 0, stream)
+        p.set_matrix(m)
+    nb, nnzb, nnzl, nnzu = matrix_counts(m)
+    npairs = nnzl
+    if op == "ilu_apply":
+        p.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+        npairs = p.ilu0_positions_size()
+    else:
+        p.jacobi_compute()
+    ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs)
+    step = {"ilu_apply": lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z),
+            "sgs_relax": lambda: p.sgs_relax(r, z, s, mode=capi.ASYNC)}[op]
+    unit_bytes, kbytes, kernel = unit_of(op, ab)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    p.set_timing(True)
+    p.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tm = p.get_timing(reset=True)
+    p.set_timing(False)
+    kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
+    ach = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    if reuse is None:
+        p.close()
+    return {"baseline_config": k, "workload": cfg["workload"], "value": s * steps / el, "unit": "sweeps/s", "steps": steps,
+            "warmup": warmup, "ms_per_step": el / steps * 1e3, "napplysweeps": s, "nbrows": nb, "block_size": bs,
+            "achieved_gbps": unit_bytes * s / (el / steps) / 1e9,
+            "roofline": {"bound": "hbm", "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes, "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
+                         "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1)},
+            "setup_s": t_setup}
+
+
+def reference_side_quality(cfg, capi, workloads, torch, dev, s):
+    """SURVEY 8(d) tier P4 beside the GPU figure, on the cpu_baseline sample (same generator, smaller grid): what
+    s+s and 10+10 sweeps of the REFERENCE loop nest (oracle ASYNC_OMP, this box's host cores, chunk 256) leave of
+    the distance to the exact triangular solves, against HIP ASYNC on the same matrix."""
+    import numpy as np
+    import oracle
+    oracle.set_num_threads(oracle.cpu_budget())
+    m = workloads.poisson3d(cfg["cpu_n"] + 2, cfg["bs"], grid=cfg["grid"])
+    r = workloads.rhs_vector(m["nbrows"] * cfg["bs"])
+    f = oracle.ilu0_factorize(m, None, 1, mode=oracle.GS_SERIAL)["iluvals"]
+    ze = oracle.ilu0_apply(m, f, r, 1, mode=oracle.GS_SERIAL)
+    nz = float(np.linalg.norm(ze))
+    dist = lambda z: float(np.linalg.norm(z - ze)) / nz
+    ref = {k: dist(oracle.ilu0_apply(m, f, r, k, mode=oracle.ASYNC_OMP, init=oracle.INIT_A_ZERO, chunk=256)) for k in (s, 10)}
+    p = capi.Prec(dev.index or 0)
+    p.set_matrix(m)
+    p.ilu0_factorize(-1)
+    rd = torch.from_numpy(r).to(dev)
+    hip = {k: dist(p.ilu0_apply(rd, k, init=capi.INIT_A_ZERO, mode=capi.ASYNC).cpu().numpy()) for k in (s, 10)}
+    p.close()
+
+    def rho(d):
+        return (d[10] / d[s]) ** (1.0 / (10 - s)) if 0 < d[10] < d[s] and s < 10 and d[10] > 1e-14 else None
+    return {"sample": "Poisson %d^3 bs=%d (the cpu_baseline sample)" % (cfg["cpu_n"], cfg["bs"]),
+            "threads": oracle.num_threads(),
+            "reference_loop_nest": {"distance_after_%d+%d" % (s, s): ref[s], "distance_after_10+10": ref[10],
+                                    "contraction_per_sweep": rho(ref)},
+            "hip_async": {"distance_after_%d+%d" % (s, s): hip[s], "distance_after_10+10": hip[10],
+                          "contraction_per_sweep": rho(hip)},
+            "note": "the reference's threaded sweep in natural order is nearly sequential Gauss-Seidel (few threads, "
+                    "chunks of 256 consecutive rows); thousands of concurrent waves make the GPU's in-place sweep "
+                    "Jacobi-like over the rows in flight: profiles/r03_async_vs_reference.txt"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +353,8 @@ def main():
     ap.add_argument("--build-sweeps", type=int, default=None)
     ap.add_argument("--op", default=None, choices=["ilu_apply", "sgs_apply", "sgs_relax", "spmv", "factor"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run only: skip the short measurements of configurations 3, 4, 5, 1")
     ap.add_argument("--cpu-sample-n", type=int, default=None)
     args = ap.parse_args()
 
@@ -313,12 +426,14 @@ def main():
         p.set_matrix(m)
         nb, nnzb, nnzl, nnzu = matrix_counts(m)
         npairs = nnzl
+        nfixed = 0
         if op in ("ilu_apply", "factor"):
             p.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
             npairs = p.ilu0_positions_size()
+            nfixed = fixed_upper_blocks(p, m, cfg["gen"])
         else:
             p.jacobi_compute()
-        ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs)
+        ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed)
         sync()
         step = {
             "ilu_apply": lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z),
@@ -329,6 +444,13 @@ def main():
         }[op]
     unit_bytes, kbytes, kernel = unit_of(op, ab)
     units_per_step = 1 if op == "spmv" else s
+    # bytes one step moves by the algorithmic count (the ASYNC-mode SGS application is one exact forward pass
+    # followed by s backward sweeps; the in-place factorisation sweeps leave the fixed upper blocks alone)
+    step_bytes = unit_bytes * units_per_step
+    if op == "sgs_apply":
+        step_bytes = ab["sgs_fwd"] + s * ab["sgs_bwd"]
+    if op == "factor":
+        kbytes = ab["factor_sweep_touched"]
 
     for _ in range(args.warmup):
         step()
@@ -365,10 +487,12 @@ def main():
                        "napplysweeps": s, "nbuildsweeps": cfg["build"], "sweep_mode": "async", "grid": cfg["grid"],
                        "replicas": world,
                        "unit_definition": "one %s = %d algorithmic bytes" % (
-                           {"ilu_apply": "L+U sweep pair", "sgs_apply": "forward+backward sweep pair",
+                           {"ilu_apply": "L+U sweep pair",
+                            "sgs_apply": "backward sweep (every step also runs ONE exact forward pass, as the reference "
+                                         "does: %d bytes, counted in achieved_gbps)" % ab["sgs_fwd"],
                             "sgs_relax": "relaxation step (ascending + descending pass)", "spmv": "product",
                             "factor": "factorisation sweep"}[op], unit_bytes)},
-            "achieved_gbps": unit_bytes * units_per_step * world / (ms_per_step * 1e-3) / 1e9,
+            "achieved_gbps": step_bytes * world / (ms_per_step * 1e-3) / 1e9,
         }
         if not dry:
             copy_gbps = measured_copy_gbps(dev)
@@ -376,20 +500,31 @@ def main():
             read_gbps = capi.measure_read_stream(m["vals"], reps=10)
             kms = tm[kernel + "_ms"] / max(tm[kernel + "_launches"], 1)
             achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            traffic = None
+            # HBM bytes per launch of the dominant kernel from the PMC passes of this configuration (separate
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command, tools/profile_round.sh): a committed
+            # record, not a measurement of this run -- traffic_source says which passes and which commit
+            traffic, traffic_source = None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
                     tj = json.load(open(tf))
                     ent = tj.get(cfg["workload"]) or (tj.get(op) if args.config == 2 and not custom else None) or {}
                     traffic = ent.get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = {"profiles": ent.get("from"), "commit": ent.get("commit"),
+                                          "kernel": ent.get("kernel")}
                 except Exception:
-                    traffic = None
+                    traffic, traffic_source = None, None
             family = ("sweepw_kernel<%d, ...>" % bs if bs in (4, 8) else
                       "sweepodd_kernel<%d, ...>" % bs if bs in (3, 5, 7) else "sweep_kernel<%d, ...>" % bs)
+            # a 64^3 scalar problem is 22 MB: it lives in the L2s / the 256 MB Infinity Cache and a sweep is an
+            # 8 us launch -- the step is bound by launch latency and cache bandwidth, not by HBM
+            cache_resident = ab["ilu_pair"] < 128e6
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "launch/L2" if cache_resident else "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "launches_per_step": (tm["lower_launches"] + tm["upper_launches"] + tm["other_launches"]) / args.steps,
                 "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                 "measured_read_stream_gbps": read_gbps, "frac_of_read_stream": achieved / read_gbps,
                 "kernel": "%s (%s pass; bhip::%s in the rocprofv3 summaries)" % (
@@ -403,6 +538,11 @@ def main():
                 "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
                 "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
                 "other_ms_per_step": tm["other_ms"] / args.steps}
+            if cache_resident:
+                out["roofline"]["note"] = ("working set %.0f MB: cache-resident, launch-latency bound (%.1f us per step "
+                                           "over %d launches); frac is against the HBM peak only for uniformity" % (
+                                               ab["ilu_pair"] / 1e6, ms_per_step * 1e3,
+                                               out["roofline"]["launches_per_step"]))
 
         def _t(fn, reps=5):
             fn()
@@ -422,10 +562,15 @@ def main():
                 tf_ = p.get_timing(reset=True)
                 p.set_timing(False)
                 fms = tf_["lower_ms"] / max(tf_["lower_launches"], 1)
+                tb = ab["factor_sweep_touched"]
                 out["factor"] = {"async_factor_ms": asf, "nbuildsweeps": cfg["build"], "sweep_ms": fms,
                                  "algorithmic_bytes_per_sweep": ab["factor_sweep"],
-                                 "achieved": ab["factor_sweep"] / (fms * 1e-3) / 1e9 if fms > 0 else 0.0,
-                                 "frac": ab["factor_sweep"] / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else 0.0}
+                                 "touched_bytes_per_sweep": tb, "fixed_upper_blocks": ab["fixed_upper"],
+                                 "achieved": tb / (fms * 1e-3) / 1e9 if fms > 0 else 0.0,
+                                 "frac": tb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else 0.0,
+                                 "note": "in-place sweeps leave upper blocks without position pairs alone (their value "
+                                         "is the matrix block): achieved / frac count the bytes the sweep touches, not "
+                                         "the every-array-once figure"}
                 ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
                 st = p.level_stats()
                 sy = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC, out=z))
@@ -434,11 +579,36 @@ def main():
                                       "note": "one exact L and U solve (mode LEVEL), and %d+%d SYNCHRONOUS sweeps "
                                               "(deterministic; the first sweep from zero needs no matrix), beside "
                                               "ms_per_step for %d+%d asynchronous sweeps" % (s, s, s, s)}
+                # what the host C++ layer applies by default (BLASTED_HIP_SWEEP_MODE unset): timed beside the metric's mode
+                dm = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z))
+                out["default_mode_apply"] = {"mode": "async", "ms": dm,
+                                             "note": "the host layer's default sweep mode is the metric's mode"}
                 out["quality"] = quality_figures(p, capi, torch, r, z, s)
+                if cfg["gen"] != "unstructured" and not args.no_cpu_baseline:
+                    try:
+                        out["quality"]["same_matrix_reference"] = reference_side_quality(cfg, capi, workloads, torch, dev, s)
+                    except Exception as e:
+                        out["quality"]["same_matrix_reference"] = {"failed": repr(e)}
                 exf = _t(lambda: p.ilu0_factorize(-1), reps=2)
                 out["exact_apply"]["exact_factor_ms"] = exf
             except Exception as e:
                 out["exact_apply"] = {"ms": None, "note": "failed: %r" % (e,)}
+        if not dry and world == 1 and args.config == 2 and not custom and not args.no_other_configs:
+            # the other BASELINE configurations, briefly (5 steps each), so that the one line the driver records
+            # carries a timed figure for every configuration; `python bench.py --config K` is the full run of each
+            others = []
+            try:
+                others.append(short_run(3, dev, stream, capi, workloads, torch, reuse=(p, m, r, z)))
+                p.close()
+                p = None
+                del m, r, z
+                torch.cuda.empty_cache()
+                for k in (4, 5, 1):
+                    others.append(short_run(k, dev, stream, capi, workloads, torch))
+                    torch.cuda.empty_cache()
+            except Exception as e:
+                others.append({"failed": repr(e)})
+            out["other_configs"] = others
         if not dry and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, op, s, unit_bytes, units_per_step)

@@ -1745,6 +1745,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "levelnowait=", 12) == 0)
+			set_syncfree_nowait(spec[12] - '0');  // measurements only: wrong results
 		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)
 			set_level_fast(spec[10] - '0');  // (2: tests -- behave as if the polling launch had given up)
 		else if (spec && std::strncmp(spec, "levelserial=", 12) == 0)

@@ -401,12 +401,16 @@ __global__ __launch_bounds__(256) void level_meta_kernel(const Pattern pat, cons
 constexpr unsigned long long SF_PENDING = 0xFFF8DEADBEEF0001ull;  // a NaN payload arithmetic never produces
 constexpr int SF_SPIN_LIMIT = 1 << 22;
 
-__global__ __launch_bounds__(256) void sf_fill_kernel(unsigned long long *x, long n)
+__global__ __launch_bounds__(256) void sf_fill_kernel(unsigned long long *x, long n, unsigned long long v)
 {
 	const long i = (long)blockIdx.x * 256 + threadIdx.x;
 	if (i < n)
-		x[i] = SF_PENDING;
+		x[i] = v;
 }
+
+// "levelnowait=1" (measurements only, WRONG results): the iterate is pre-filled with zeros instead of the pending
+// pattern, so no row ever waits -- what a single-launch pass costs as a pure stream, without its dependencies
+int g_sf_nowait = 0;
 
 __device__ __forceinline__ double sf_load(const double *p)
 {
@@ -952,7 +956,12 @@ void launch_syncfree_fill(double *x, long n, hipStream_t s)
 	if (n <= 0)
 		return;
 	hipLaunchKernelGGL(sf_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-	                   reinterpret_cast<unsigned long long *>(x), n);
+	                   reinterpret_cast<unsigned long long *>(x), n, g_sf_nowait ? 0ull : SF_PENDING);
+}
+
+void set_syncfree_nowait(int on)
+{
+	g_sf_nowait = on != 0;
 }
 
 // One exact in-order pass as ONE persistent launch.  a.xout must have been filled by

@@ -284,6 +284,22 @@ __global__ __launch_bounds__(256) void sfw_kernel(const SweepArgs a, const int *
 	}
 }
 
+// ---- round 3: what bounds this pass, measured (tools/exact_solve_ab.py, profiles/r03_exact_solve_experiments.txt) ----
+// With the iterate pre-filled with zeros instead of the pending pattern (tuning "levelnowait=1": nobody waits, wrong
+// results) the two passes of the 256^3 bs=4 application take 4.4-4.75 ms of the 5.55-5.7 ms: the dependencies cost
+// about 1.0 ms (0.65 us per level and triangle), the rest is the stream itself -- which moves more than the
+// triangular sweeps' count: a 32-byte head per row, the pending fill of each output, the right-hand side gathered by
+// row number and z scattered back to natural order in 32-byte pieces.  At 128^3 it is the other way round (0.70 of
+// 1.71 ms is stream, 1.3 us per level).  Two restructurings were built on this kernel, verified bit-identical to it,
+// measured and removed: (1) a PERSISTENT grid (as many workgroups as are resident, wave w taking the row steps
+// w, w + W, ...) with the next step's blocks requested before the current step's polls -- loads return in order, so
+// every poll after the first waits for the prefetch: 7.0 ms; (2) the same with only the next step's INDEX loads in
+// flight -- no launch and no index round trip per step, but the loop's carried state costs 18 registers (86 / 78
+// instead of 68 / 56: 5-6 resident waves instead of 7-8): 6.2 ms, also with nobody waiting (5.2 against 4.75).
+// Start-up is not what a step costs; resident waves x bytes per wave are.  (3) One block slot per row in the upper
+// pass (8 rows per wave instead of 4): 4.40 against 4.55 ms with nobody waiting, 5.59 against 5.57 ms with the
+// dependencies -- not kept (it would also change the summation order).
+
 // ---- odd block sizes 3, 5, 7 (the lane layout of kernels_sweepodd.hip) -----------------------------------
 // G = 8 / 16 / 32 lanes per row, L = (bs*bs+1)/2 of them hold a block as 16 bytes per lane, the stride-bs
 // reduction goes through a wave-private LDS tile.  One row step per wave, up to eight blocks of a row
@@ -464,7 +480,6 @@ __global__ __launch_bounds__(256) void sfodd_kernel(const SweepArgs a, const int
 
 int g_levelw_enabled = 1;
 int g_levelw_variant = 0;  // 0: one row step per wave (default), 1: two
-
 }  // namespace
 
 void set_levelw_enabled(int on)

@@ -78,4 +78,7 @@ def test_algorithmic_bytes_match_survey():
     from blasted_amd import workloads
     m = workloads.poisson3d(8, 4, grid="uniform")
     nb, nnzb, nnzl, nnzu = bench.matrix_counts(m)
-    assert bench.pattern_bytes(nb, nnzb, nnzl, nnzu, nnzl, 4) == bench.algorithmic_bytes(6, 4)
+    assert bench.pattern_bytes(nb, nnzb, nnzl, nnzu, nnzl, 4, nfixed=nnzu) == bench.algorithmic_bytes(6, 4)
+    # the bytes an in-place sweep touches once the pair-less upper blocks are left alone: 3 arrays x their blocks less
+    ab6 = bench.algorithmic_bytes(6, 4)
+    assert ab6["factor_sweep"] - ab6["factor_sweep_touched"] == 3 * nnzu * 128
