@@ -509,12 +509,15 @@ static int g_factor_skip_fixed = 1;
 // reference's semantics, default) or as napplysweeps asynchronous sweeps
 static int g_sgs_exact_fwd = 1;
 
+static int g_gather_probe = 0;  // tuning "gatherprobe=1": see SweepArgs::probe
+
 static SweepArgs base_args(blasted_hip_prec p)
 {
 	SweepArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.pat = p->pat;
 	a.interleave = g_interleave;
+	a.probe = g_gather_probe;
 	a.xcd_shift = g_xcd_shift;
 	a.a = 1.0;
 	a.b = 0.0;
@@ -1745,6 +1748,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "gatherprobe=", 12) == 0)
+			g_gather_probe = spec[12] != '0';  // measurements only: wrong results
 		else if (spec && std::strncmp(spec, "levelnowait=", 12) == 0)
 			set_syncfree_nowait(spec[12] - '0');  // measurements only: wrong results
 		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)

@@ -70,6 +70,8 @@ struct SweepArgs {
 	int descending;         // row order of the sweep
 	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp), default 4
 	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
+	int probe;              // measurements only (tuning "gatherprobe=1", WRONG results): kernels_sweepodd.hip gathers
+	                        // every block's x segment from the row's OWN position -- the sweep at its algorithmic traffic
 };
 
 // Level schedule of a pattern (kernels_level.hip): rows sorted by dependency depth

@@ -401,9 +401,10 @@ __global__ void scaled_copy_kernel(const Pattern pat, const double *avals, const
 	const int irow = lo, col = pat.bcolind[jpos];
 	double v = avals[idx];
 	if (scale) {
-		if (BS == 1)
-			v = scale[irow] * v * scale[col];
-		else
+		if (BS == 1) {  // (a s_i) s_j
+			v *= scale[irow];
+			v *= scale[col];
+		} else
 			v *= scale[(long)irow * BS + r] * scale[(long)col * BS + c];
 	}
 	ilu[idx] = v;
@@ -631,9 +632,10 @@ __global__ __launch_bounds__(256) void sff_factor_kernel(const FactorArgs a, con
 			const int col = a.pat.bcolind[jpos];
 			double s = active ? a.avals[(long)jpos * BS2 + e] : 0.0;
 			if (a.scale && active) {
-				if (BS == 1)
-					s *= a.scale[irow] * a.scale[col];
-				else
+				if (BS == 1) {  // (a s_i) s_j, two roundings, as the reference's scalar kernel and every other form here
+					s *= a.scale[irow];
+					s *= a.scale[col];
+				} else
 					s *= a.scale[(long)irow * BS + r] * a.scale[(long)col * BS + c];
 			}
 			bool ready = true;

@@ -134,8 +134,10 @@ __global__ __launch_bounds__(256) void factor1_kernel(const FactorArgs a)
 			const int row = r0 + lo, col = s_col[q];
 			if (col < row)
 				s_dv[q] = a.in[a.pat.diagind[col]];
-			if (a.scale)
-				s_av[q] *= a.scale[row] * a.scale[col];
+			if (a.scale) {  // (a s_i) s_j, two roundings, as src/kernels/kernels_ilu0_factorize.hpp:29-32
+				s_av[q] *= a.scale[row];
+				s_av[q] *= a.scale[col];
+			}
 		}
 	}
 	__syncthreads();
@@ -153,8 +155,10 @@ __global__ __launch_bounds__(256) void factor1_kernel(const FactorArgs a)
 				s = s_av[le];
 			else {
 				s = a.avals[jpos];
-				if (a.scale)
-					s *= a.scale[irow] * a.scale[col];
+				if (a.scale) {
+					s *= a.scale[irow];
+					s *= a.scale[col];
+				}
 			}
 			const int kb = staged ? s_pp[le] : a.posptr[jpos];
 			const int ke = staged ? s_pp[le + 1] : a.posptr[jpos + 1];

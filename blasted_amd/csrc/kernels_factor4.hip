@@ -528,18 +528,29 @@ bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream
 	if (a.pat.max_row_len > X4_MAXE || ls.max_lower > X4_MAXL)
 		return false;
 	if (ls.f4_maxpairs < 0) {
+		// Nothing of the cache (f4_maxpairs, f4_maxtodo, f4_grid, f4_desc) is committed before the plans exist on the
+		// device: a failure on the way (out of memory for the ~1 GB plan array at 256^3, a failed launch) leaves
+		// f4_maxpairs < 0 and frees what was allocated, so the next factorisation tries again instead of launching a
+		// plan kernel with a null plan pointer.
 		int *d = nullptr;
-		BHIP_CHECK(tracked_malloc(&d, 2 * sizeof(int)));
-		BHIP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), s));
-		hipLaunchKernelGGL(max_pairs_kernel, dim3((unsigned)((a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a.pat,
-		                   a.posptr, d);
-		int h[2] = {0, 0};
-		BHIP_CHECK(hipMemcpyAsync(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-		BHIP_CHECK(hipStreamSynchronize(s));
-		(void)tracked_free(d);
-		ls.f4_maxpairs = h[0];
-		ls.f4_maxtodo = h[1];
-		if (ls.f4_maxpairs <= X4_MAXP) {
+		int2 *wgpos = nullptr;
+		int *desc = nullptr;
+		try {
+			BHIP_CHECK(tracked_malloc(&d, 2 * sizeof(int)));
+			BHIP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), s));
+			hipLaunchKernelGGL(max_pairs_kernel, dim3((unsigned)((a.pat.nbrows + 255) / 256)), dim3(256), 0, s, a.pat,
+			                   a.posptr, d);
+			int h[2] = {0, 0};
+			BHIP_CHECK(hipMemcpyAsync(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+			BHIP_CHECK(hipStreamSynchronize(s));
+			(void)tracked_free(d);
+			d = nullptr;
+			const int maxpairs = h[0], maxtodo = h[1];
+			if (maxpairs > X4_MAXP) {
+				ls.f4_maxtodo = maxtodo;
+				ls.f4_maxpairs = maxpairs;
+				return false;
+			}
 			std::vector<int2> wg;
 			for (int l = 0; l < ls.nlevels; l++)
 				for (int q = ls.ptr[(size_t)l]; q < ls.ptr[(size_t)l + 1]; q += rpwg)
@@ -547,23 +558,36 @@ bool build_row_plans(const FactorArgs &a, LevelSchedule &ls, int rpwg, hipStream
 			if ((long)wg.size() * rpwg > 2L * a.pat.nbrows + 4096) {
 				// narrow levels (a banded / one-dimensional ordering): padding every level to a workgroup would
 				// multiply the plan array -- such a pattern keeps the kernels that take rows as they come
+				ls.f4_maxtodo = maxtodo;
 				ls.f4_maxpairs = 1 << 30;
 				return false;
 			}
-			ls.f4_grid = (int)wg.size();
-			int2 *wgpos = nullptr;
+			const int grid = (int)wg.size();
 			BHIP_CHECK(tracked_malloc(&wgpos, sizeof(int2) * wg.size()));
 			BHIP_CHECK(hipMemcpyAsync(wgpos, wg.data(), sizeof(int2) * wg.size(), hipMemcpyHostToDevice, s));
-			const long nd = (long)ls.f4_grid * rpwg * X4_DESC;
-			BHIP_CHECK(tracked_malloc(&ls.f4_desc, sizeof(int) * (size_t)nd));
+			const long nd = (long)grid * rpwg * X4_DESC;
+			BHIP_CHECK(tracked_malloc(&desc, sizeof(int) * (size_t)nd));
 			hipLaunchKernelGGL(x4_describe_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a, ls.meta, wgpos,
-			                   ls.f4_grid, rpwg, ls.f4_desc);
+			                   grid, rpwg, desc);
 			BHIP_CHECK(hipGetLastError());
 			BHIP_CHECK(hipStreamSynchronize(s));
 			(void)tracked_free(wgpos);
+			wgpos = nullptr;
+			ls.f4_desc = desc;
+			ls.f4_grid = grid;
+			ls.f4_maxtodo = maxtodo;
+			ls.f4_maxpairs = maxpairs;  // last: this is what marks the cache valid
+		} catch (...) {
+			if (d)
+				(void)tracked_free(d);
+			if (wgpos)
+				(void)tracked_free(wgpos);
+			if (desc)
+				(void)tracked_free(desc);
+			throw;
 		}
 	}
-	return ls.f4_maxpairs <= X4_MAXP;
+	return ls.f4_maxpairs <= X4_MAXP && ls.f4_desc != nullptr;
 }
 
 // The exact factorisation of a bs = 4 matrix (either block layout) with stencil-like rows as one launch (see

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 				const bool isdiag = (jj == q.dg);
 				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {
 					const int cidx = jj - jlo;
-					const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+					if (a.probe)
+						col = r0 + q.lr;  // (timing experiment: no gather, the row's own segment)
 					q.xv[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
 				}
 			}
@@ -185,7 +187,9 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 						v4[k] = NT ? load16u_nt(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff))
 						           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
 						const int cidx = jj - jlo;
-						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						if (a.probe)
+							col = r0 + q.lr;
 						x4[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
 					}
 				}

@@ -3,9 +3,10 @@
 //
 // Type strings and dispatch rules are the reference's: `ilu0` -> async factor + async apply,
 // `seqilu0` -> sequential both, `sfilu0` -> sequential factor, `sapilu0` -> sequential apply; bs == 1
-// always selects the scalar operators.  Types outside the preconditioner-apply hot path (cscbgs,
-// level_sgs, async_level_ilu0) are recognised by solverTypeFromString but create_preconditioner
-// rejects them with std::invalid_argument on this backend.
+// always selects the scalar operators; `level_sgs` and `async_level_ilu0` are the exact (level-scheduled)
+// operators, `gs` the chaotic forward relaxation, `jacobi`, `none`.  The one type outside the
+// preconditioner-apply hot path, `cscbgs` (CSC storage), is recognised by solverTypeFromString but
+// create_preconditioner rejects it with std::invalid_argument on this backend.
 #pragma once
 
 #include <string>

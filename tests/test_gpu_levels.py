@@ -136,25 +136,29 @@ def test_level_schedule_deep_graph_takes_the_in_order_pass(shape):
 
 
 @pytest.mark.parametrize("case", CASES + ["poisson9_bs8", "random_bs5", "poisson8_bs7_row"])
-def test_exact_factorisation_single_launch_equals_per_level(golden, case):
+@pytest.mark.parametrize("usescale", [False, True])
+def test_exact_factorisation_single_launch_equals_per_level(golden, case, usescale):
     """The exact factorisation as ONE launch whose rows wait for the rows they depend on (factorsf) is the same
     arithmetic in the same order as one launch per level: bit-identical factors, for every block size and layout
     (factorsf=3 forces the general kernel everywhere; the default (1) and factorsf=2 take the matrix-core kernel
     at bs = 4 where it applies: its products are summed in the order of the general kernels)."""
+    if usescale and case.startswith("random"):
+        pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
     m = matrices(golden)[case]()
     p = make_prec(m)
     res = {}
     try:
         for k in ("0", "3", "2", "1"):
             capi.set_tuning("factorsf=" + k)
-            p.ilu0_factorize(-1)
+            p.ilu0_factorize(-1, usescale=usescale)
             res[k] = p.get_iluvals()
     finally:
         capi.set_tuning("factorsf=1")
+    # (with symmetric scaling too: every form scales an entry as (a s_i) s_j, the reference's two roundings)
     assert np.array_equal(res["0"], res["3"])
     assert np.array_equal(res["0"], res["2"]) and np.array_equal(res["0"], res["1"])
     assert p.level_stats()["syncfree_aborts"] == 0
-    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    f = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=usescale)["iluvals"]
     assert rel(res["2"], f) < TOL
     p.close()
 
