@@ -477,21 +477,23 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 	return launch_level_sweep(a, part, post, dsrc, ls, p->stream);
 }
 
-// "interleave=1" (environment BLASTED_HIP_INTERLEAVE=1): the rows a workgroup of the bs=4/8 column-major sweep
-// computes side by side are taken a step count apart, so a row's predecessor belongs to the previous step
-// (already stored) instead of to the same step (stale): Gauss-Seidel-like along a chunk, as the reference's
-// threads are inside their chunks.  256^3 bs=4, distance to the exact solves after 3+3 / 10+10 sweeps
-// 0.162 / 5.6e-4 -> 0.063 / 1.6e-5: contraction per sweep 0.444 -> 0.306, i.e. 1.46x fewer sweeps for the same
-// accuracy, at +13..15 % time per sweep -- the better preconditioner per unit of time, and the slower one
-// per sweep, which is what the headline metric counts: off by default, on for accuracy per second.
-// Where the +15 % comes from (round 1, tools/probes): the timing-only variant without gathers pays +16 % for the
+// "interleave=1" (default from round 3 on) / "interleave=0" (environment BLASTED_HIP_INTERLEAVE=0|1): the rows a
+// workgroup of the bs=4/8 column-major sweep computes side by side are taken a step count apart, so a row's
+// predecessor belongs to the previous step (already stored) instead of to the same step (stale): Gauss-Seidel-like
+// along a chunk, as the reference's threads are inside their chunks.  256^3 bs=4, distance to the exact solves after
+// 3+3 / 10+10 sweeps 0.161 / 5.6e-4 -> 0.063 / 1.6e-5: contraction per sweep 0.445 -> 0.305, i.e. 1.45x fewer sweeps
+// for the same accuracy, at +12 % time per sweep pair: 43 ms instead of 56 ms to bring the distance to 1e-6 (7.0
+// against 7.7 ms at 128^3; profiles/r03_sweep_order_quality.txt).  Rounds 1-2 kept it off because the headline
+// metric counts sweeps per second; the default is now chosen by what a sweep is worth as a preconditioner per
+// millisecond, and bench.py reports the natural row order beside it (`sweep_order_alternative`).
+// Where the +12..15 % comes from (round 1, tools/probes): the timing-only variant without gathers pays +16 % for the
 // 32-byte rhs / result pieces a step now takes 4 rows apart; storing the triangles in sweep order does not
 // help (the value stream was not the problem); and sweeping the symmetrically permuted system, on which every
 // access is contiguous again, still pays +10 % per sweep pair -- fresh neighbours are lines another wave has
 // just written -- plus two vector permutation passes per application.  Both were built, measured and removed.
 static int g_interleave = [] {
 	const char *e = std::getenv("BLASTED_HIP_INTERLEAVE");
-	return (e && e[0] == '1') ? 1 : 0;
+	return (e && e[0] == '0') ? 0 : 1;
 }();
 
 // tuning ("xcdsuper=N", N a power of two): the XCDs take turns on super-chunks of N consecutive chunks (lanes.hpp)

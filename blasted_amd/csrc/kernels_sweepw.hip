@@ -89,9 +89,17 @@ __device__ __forceinline__ void sc_store(char *p, const double v)
 // straight-line passes, one memory round trip per group instead of one per block, for patterns with longer
 // rows (unstructured meshes); the group's registers take the kernel to 74-78 VGPRs, 6 waves per SIMD, which
 // is why it is a separate instantiation chosen by the pattern's longest row.
+// (Round 3, built, verified and removed: "Gauss-Seidel inside the wave" -- after the parallel phase the wave walked its
+// eight rows in sweep order and corrected each row's sum for its in-wave predecessor: the neighbour's NEW value by a
+// lane permute, minus the gathered old one, times the coupling block still in registers.  Correct, 52-64 registers,
+// better first sweeps (distance to the exact solves after 3+3 sweeps 0.092 instead of 0.161 at 256^3) but the same
+// asymptotic contraction (0.439 against 0.445: the slow error modes sit in the couplings between waves, not inside
+// them), and the seven dependent permute-and-reduce rounds cost 21 % on the lower and 81 % on the upper sweep:
+// profiles/r03_sweep_order_quality.txt.  The interleaved row order below does better for 12 %.)
 template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false, bool LR = false>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
+
 	using Ge = WGeo<BS, NBV>;
 	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
 	constexpr int CAP = 8 * RCHUNK;  // staged column indices
@@ -334,44 +342,48 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			const double rv0 = r2[u].x * s2[u].x, rv1 = r2[u].y * s2[u].y;
 
 			double o0, o1;
-			if (POST == POST_SUB) {
-				o0 = rv0 - acc0;
-				o1 = rv1 - acc1;
-			} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
-				const double w0 = (POST == POST_D_SUB) ? rv0 - acc0 : acc0;  // rows 2h, 2h+1 of the vector D multiplies
-				const double w1 = (POST == POST_D_SUB) ? rv1 - acc1 : acc1;
-				// this lane needs component c of that vector: rows 2(c/2), 2(c/2)+1 are held by the lanes
-				// whose row-pair index h equals c/2; every aligned group of HB lanes contains all h
-				double wc;
-				if (BS == 4) {
-					const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
-					const double a10 = dpp_mov<0x55>(w0), a11 = dpp_mov<0x55>(w1);  // quad_perm [1,1,1,1]
-					const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
-					const double s0 = b2 ? a10 : a00, s1 = b2 ? a11 : a01;
-					wc = b1 ? s1 : s0;
+			// the post-operation on the row's sum (acc0, acc1 = rows 2h, 2h+1 of sum_j A_ij x_j, in every lane)
+			auto post_op = [&](const double s0, const double s1) {
+				if (POST == POST_SUB) {
+					o0 = rv0 - s0;
+					o1 = rv1 - s1;
+				} else if (POST == POST_D_SUB || POST == POST_SUB_D) {
+					const double w0 = (POST == POST_D_SUB) ? rv0 - s0 : s0;  // rows 2h, 2h+1 of the vector D multiplies
+					const double w1 = (POST == POST_D_SUB) ? rv1 - s1 : s1;
+					// this lane needs component c of that vector: rows 2(c/2), 2(c/2)+1 are held by the lanes
+					// whose row-pair index h equals c/2; every aligned group of HB lanes contains all h
+					double wc;
+					if (BS == 4) {
+						const double a00 = dpp_mov<0x00>(w0), a01 = dpp_mov<0x00>(w1);  // quad_perm [0,0,0,0]
+						const double a10 = dpp_mov<0x55>(w0), a11 = dpp_mov<0x55>(w1);  // quad_perm [1,1,1,1]
+						const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
+						const double t0 = b2 ? a10 : a00, t1 = b2 ? a11 : a01;
+						wc = b1 ? t1 : t0;
+					} else {
+						const int src = (lane & ~(HB - 1)) | (c >> 1);
+						const double t0 = __shfl(w0, src, 64), t1 = __shfl(w1, src, 64);
+						wc = (c & 1) ? t1 : t0;
+					}
+					// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
+					const double p0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
+					const double p1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
+					if (POST == POST_D_SUB) {
+						o0 = p0;
+						o1 = p1;
+					} else {
+						o0 = rv0 - p0;
+						o1 = rv1 - p1;
+					}
 				} else {
-					const int src = (lane & ~(HB - 1)) | (c >> 1);
-					const double t0 = __shfl(w0, src, 64), t1 = __shfl(w1, src, 64);
-					wc = (c & 1) ? t1 : t0;
+					o0 = a.a * s0;
+					o1 = a.a * s1;
+					if (a.b != 0.0) {
+						o0 += a.b * rv0;
+						o1 += a.b * rv1;
+					}
 				}
-				// D lives in block slot 0 only (zero elsewhere): the all-reduce is its column sum
-				const double p0 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d0 * wc);
-				const double p1 = allreduce_bits<Ge::HBITS, Ge::GBITS>(d1 * wc);
-				if (POST == POST_D_SUB) {
-					o0 = p0;
-					o1 = p1;
-				} else {
-					o0 = rv0 - p0;
-					o1 = rv1 - p1;
-				}
-			} else {
-				o0 = a.a * acc0;
-				o1 = a.a * acc1;
-				if (a.b != 0.0) {
-					o0 += a.b * rv0;
-					o1 += a.b * rv1;
-				}
-			}
+			};
+			post_op(acc0, acc1);
 
 			if (ok[u] && slot == 0 && q < HB) {
 				double2_t o2;

@@ -44,7 +44,8 @@ public:
 	void bind(const CRawBSRMatrix<double, int> &mat, int bs, StorageOptions stor);
 	blasted_hip_prec_s *get() const { return h; }
 	static void check(int rc);
-	/// how ilu0 / sgs apply their sweeps: BLASTED_HIP_DETERMINISTIC unless BLASTED_HIP_SWEEP_MODE says otherwise
+	/// how ilu0 / sgs apply their sweeps: BLASTED_HIP_ASYNC (the reference's chaotic sweeps) unless set_sweep_mode()
+	/// or BLASTED_HIP_SWEEP_MODE says otherwise
 	static int sweep_mode();
 	static int default_device();
 
@@ -52,6 +53,14 @@ private:
 	blasted_hip_prec_s *h;
 	bool pattern_set;
 };
+
+/// "async" | "deterministic" | "exact" -> the C ABI's mode; throws std::invalid_argument otherwise
+int sweep_mode_from_string(const char *m);
+/// process-wide choice of how the asynchronous types apply their sweeps (overrides BLASTED_HIP_SWEEP_MODE; NULL or
+/// "" removes the override).  "async": the reference's chaotic sweeps (default; flexible outer solvers);
+/// "deterministic": synchronous sweeps, a fixed operator (any Krylov method); "exact": level-scheduled solves.
+void set_sweep_mode(const char *m);
+const char *sweep_mode_name();
 
 }  // namespace detail
 

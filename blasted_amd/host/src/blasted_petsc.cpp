@@ -615,12 +615,47 @@ PetscErrorCode setup_localpreconditioner_blasted(KSP ksp, Blasted_data *const bc
 	return ierr;
 }
 
+/// Not a reference option: -blasted_sweep_mode async|deterministic|exact chooses how the asynchronous types (ilu0,
+/// sgs) apply their sweeps (operators.cpp, HipOperator::sweep_mode; default async = the reference's chaotic sweeps).
+/// And a notice, once per set-up, when chaotic sweeps meet an outer Krylov method that assumes a fixed
+/// preconditioner: on this GPU the operator differs from one application to the next far more than under the
+/// reference's few threads ("Which outer solver each mode supports").
+static PetscErrorCode sweep_mode_option_and_notice(KSP ksp, const Blasted_data_list *const bctx)
+{
+	char mstr[BLASTED_OPT_STRLEN];
+	PetscBool set = PETSC_FALSE;
+	PetscOptionsGetString(NULL, NULL, "-blasted_sweep_mode", mstr, BLASTED_OPT_STRLEN, &set);
+	if (set)
+		blasted::detail::set_sweep_mode(mstr);  // (throws std::invalid_argument on anything else, like a bad -blasted_pc_type)
+	bool chaotic = false;  // a type whose APPLICATION runs asynchronous sweeps
+	for (const Blasted_data *node = bctx->ctxlist; node != NULL; node = node->next)
+		chaotic = chaotic || node->prectype == BLASTED_ILU0 || node->prectype == BLASTED_SFILU0 ||
+		          node->prectype == BLASTED_SGS;
+	if (!chaotic || std::strcmp(blasted::detail::sweep_mode_name(), "async") != 0)
+		return 0;
+	KSPType kt = NULL;
+	PetscErrorCode ierr = KSPGetType(ksp, &kt); CHKERRQ(ierr);
+	if (!kt)
+		return 0;
+	static const char *const flexible[] = {"fgmres", "gcr", "richardson", "preonly", "fcg", "pipefgmres", "pipefcg",
+	                                       "pipegcr", "fbcgs", "fbcgsr", "pipefcg"};
+	for (const char *f : flexible)
+		if (std::strcmp(kt, f) == 0)
+			return 0;
+	std::printf("setup_blasted_stack(): NOTE: -ksp_type %s assumes a fixed preconditioner, and the asynchronous sweeps of "
+	            "this backend are a different operator at every application; with few sweeps on a large subdomain "
+	            "the outer iteration can stall or diverge.  Use a flexible method (fgmres, gcr), or "
+	            "-blasted_sweep_mode deterministic (synchronous sweeps) / exact (level-scheduled solves).\n", kt);
+	return 0;
+}
+
 PetscErrorCode setup_blasted_stack(KSP ksp, Blasted_data_list *const bctx)
 {
 	BlastedFactory *factory = new SRFactory<double, int>();
 	bctx->bfactory = (void *)factory;
 	bctx->_defaultfactory = 1;
-	return setup_blasted_stack_ext(ksp, factory, bctx);
+	PetscErrorCode ierr = setup_blasted_stack_ext(ksp, factory, bctx); CHKERRQ(ierr);
+	return sweep_mode_option_and_notice(ksp, bctx);
 }
 
 void computeTotalTimes(Blasted_data_list *const bctv)
@@ -696,6 +731,7 @@ namespace blasted {
 int setup_blasted_stack_ext(KSP ksp, const FactoryBase<double, int> &factory, Blasted_data_list *const bctx)
 {
 	bctx->bfactory = (void *)&factory;
-	return ::setup_blasted_stack_ext(ksp, &factory, bctx);
+	PetscErrorCode ierr = ::setup_blasted_stack_ext(ksp, &factory, bctx); CHKERRQ(ierr);
+	return sweep_mode_option_and_notice(ksp, bctx);
 }
 }  // namespace blasted

@@ -44,21 +44,31 @@ int HipOperator::default_device()
 	return 0;
 }
 
+// process-wide override of the sweep mode (-1: none): blasted::detail::set_sweep_mode, the PCSHELL glue's
+// -blasted_sweep_mode option
+static int g_sweep_mode_override = -1;
+
 int HipOperator::sweep_mode()
 {
-	// How the asynchronous types (ilu0, sgs) APPLY their sweeps -- BLASTED_HIP_SWEEP_MODE:
-	//  * "deterministic" (default): synchronous Jacobi sweeps at the configured counts (SGS: after the exact
-	//    forward half the reference has too).  A fixed linear operator, bit-identical from call to call.  Inside
-	//    BiCGStab / CG / plain GMRES the in-place asynchronous sweeps of thousands of concurrent waves differ
-	//    enough between two applications to make the iteration diverge (256^3 Poisson, bs = 4, 3 and 5 sweeps:
-	//    profiles/r02_scope_ab.txt), where the reference's nearly sequential threaded sweeps do not; the same
-	//    number of synchronous sweeps converges, and costs less (their first sweep from zero needs no matrix).
-	//  * "async": the reference's chaotic in-place sweeps -- what bench.py measures; for flexible outer
-	//    iterations (FGMRES, pseudo-time stepping with nonlinear updates).
+	// How the asynchronous types (ilu0, sgs) APPLY their sweeps -- BLASTED_HIP_SWEEP_MODE / set_sweep_mode():
+	//  * "async" (default from round 3 on; it was "deterministic" in round 2): the reference's chaotic in-place
+	//    sweeps at the configured counts -- its semantics, and the mode bench.py measures.  The operator is then a
+	//    slightly different one at every application (thousands of waves race where the reference has a handful of
+	//    threads walking their chunks in order): measured on the Poisson test (profiles/r03_solve_compare_gcr.txt)
+	//    it preconditions the reference's FLEXIBLE solver (GCR, tests/solvers.cpp:247-352; PETSc: fgmres, gcr) at
+	//    1 .. 10 sweeps -- 940 / 515 / 456 iterations at 3 / 5 / 10 sweeps against 456 with exact solves at 160^3 --
+	//    and pseudo-time stepping with Richardson, but inside a NON-flexible Krylov method (bcgs, plain gmres, cg)
+	//    few sweeps on a large grid make the iteration diverge (160^3 and 256^3: 1, 3, 5 sweeps), which the small
+	//    cases of the reference's own tests (2dcyl1, 10 / 15 sweeps) do not show.
+	//  * "deterministic": synchronous Jacobi sweeps at the configured counts (SGS: after the exact forward half the
+	//    reference has too).  A FIXED linear operator, bit-identical from call to call, for non-flexible Krylov
+	//    methods: 129 BiCGStab iterations at 160^3 with 3 sweeps against 115 with exact solves.
 	//  * "exact": every application as exact level-scheduled passes, whatever the sweep count -- the limit the
-	//    sweeps converge to, and on this GPU cheaper than three of them.
+	//    sweeps converge to, a fixed operator too, and on this GPU cheaper than three sweeps.
 	// Legacy switches: BLASTED_HIP_EXACT_APPLY=1 = "exact", BLASTED_HIP_SYNC_SWEEPS=1 = synchronous sweeps in
 	// every entry point (factorisation and relaxations too: the parity tests' mode).
+	if (g_sweep_mode_override >= 0)
+		return g_sweep_mode_override;
 	const char *x = std::getenv("BLASTED_HIP_EXACT_APPLY");
 	if (x && std::atoi(x) != 0)
 		return BLASTED_HIP_LEVEL;
@@ -66,13 +76,35 @@ int HipOperator::sweep_mode()
 	if (e && std::atoi(e) != 0)
 		return BLASTED_HIP_JACOBI_SYNC;
 	const char *m = std::getenv("BLASTED_HIP_SWEEP_MODE");
-	if (m && std::strcmp(m, "async") == 0)
+	if (m)
+		return sweep_mode_from_string(m);
+	return BLASTED_HIP_ASYNC;
+}
+
+int sweep_mode_from_string(const char *m)
+{
+	if (std::strcmp(m, "async") == 0)
 		return BLASTED_HIP_ASYNC;
-	if (m && std::strcmp(m, "exact") == 0)
+	if (std::strcmp(m, "exact") == 0)
 		return BLASTED_HIP_LEVEL;
-	if (m && std::strcmp(m, "deterministic") != 0 && std::strcmp(m, "sync") != 0)
-		throw std::invalid_argument("BLASTED_HIP_SWEEP_MODE must be deterministic, async or exact");
-	return BLASTED_HIP_DETERMINISTIC;
+	if (std::strcmp(m, "deterministic") == 0 || std::strcmp(m, "sync") == 0)
+		return BLASTED_HIP_DETERMINISTIC;
+	throw std::invalid_argument("sweep mode must be async, deterministic or exact");
+}
+
+void set_sweep_mode(const char *m)
+{
+	g_sweep_mode_override = (m && *m) ? sweep_mode_from_string(m) : -1;
+}
+
+const char *sweep_mode_name()
+{
+	switch (HipOperator::sweep_mode()) {
+	case BLASTED_HIP_ASYNC: return "async";
+	case BLASTED_HIP_LEVEL: return "exact";
+	case BLASTED_HIP_JACOBI_SYNC: return "sync";
+	default: return "deterministic";
+	}
 }
 
 // the mode for entry points that keep the reference's chaotic form by default: the factorisation sweeps (their

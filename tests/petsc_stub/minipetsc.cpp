@@ -300,8 +300,17 @@ PetscErrorCode KSPSetOperators(KSP ksp, Mat A, Mat P)
 	return 0;
 }
 
+PetscErrorCode KSPGetType(KSP ksp, KSPType *type)
+{
+	*type = ksp->h.type.c_str();
+	return 0;
+}
+
 PetscErrorCode KSPSetFromOptions(KSP ksp)
 {
+	ksp->h.type = "gmres";  // PETSc's default for a KSP that is asked for its options
+	if (const std::string *t = find_option("-ksp_type"))
+		ksp->h.type = *t;
 	if (const std::string *t = find_option("-pc_type"))
 		ksp->pc->h.type = *t;
 	if (const std::string *t = find_option("-sub_pc_type"))

@@ -91,6 +91,8 @@ PetscErrorCode KSPCreate(MPI_Comm, KSP *);
 PetscErrorCode KSPSetOperators(KSP, Mat, Mat);
 PetscErrorCode KSPSetFromOptions(KSP); /* -pc_type, -sub_pc_type / -ksp_pc_type (the inner PC's type) */
 PetscErrorCode KSPGetPC(KSP, PC *);
+typedef const char *KSPType;
+PetscErrorCode KSPGetType(KSP, KSPType *); /* -ksp_type of the outermost KSP (PETSc's default: gmres); inner ones: preonly */
 PetscErrorCode KSPSetUp(KSP);
 PetscErrorCode KSPGetOperators(KSP, Mat *, Mat *);
 PetscErrorCode KSPDestroy(KSP *);

@@ -107,9 +107,9 @@ def test_exact_apply_switch():
     for k in ("BLASTED_HIP_EXACT_APPLY", "BLASTED_HIP_SWEEP_MODE", "BLASTED_HIP_SYNC_SWEEPS"):
         env.pop(k, None)
     r0 = subprocess.run(base, capture_output=True, text=True, timeout=300, env=env)
-    assert r0.returncode != 0   # one (synchronous) sweep does not get there in 60 iterations
-    ra = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(env, BLASTED_HIP_SWEEP_MODE="async"))
-    assert ra.returncode != 0   # nor does one asynchronous sweep
+    assert r0.returncode != 0   # one asynchronous sweep (the default mode) does not get there in 60 iterations
+    ra = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(env, BLASTED_HIP_SWEEP_MODE="deterministic"))
+    assert ra.returncode != 0   # nor does one synchronous sweep
     for switch in ({"BLASTED_HIP_EXACT_APPLY": "1"}, {"BLASTED_HIP_SWEEP_MODE": "exact"}):
         r1 = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(env, **switch))
         assert r1.returncode == 0, r1.stdout + r1.stderr
@@ -118,7 +118,7 @@ def test_exact_apply_switch():
 @pytest.mark.parametrize("sweep_mode", ["async", "deterministic"])
 def test_native_solve_in_both_product_modes(sweep_mode):
     """the reference's threaded case (ThreadedBSR4ILU0Colmajor, 10 build / 15 apply sweeps) with the reference's
-    chaotic sweeps and with the default deterministic ones"""
+    chaotic sweeps (the default) and with deterministic (synchronous) ones"""
     args = [DRIVER, "--fact_init_type", "init_original", "--apply_init_type", "init_zero",
             "--mat_file", os.path.join(G, "2dcyl1.mtx"), "--b_file", os.path.join(G, "2dcyl1_b.mtx"),
             "--x_file", os.path.join(G, "2dcyl1_x.mtx"), "--solver_tol", "1e-12", "--test_tol", "1e-8",

@@ -776,7 +776,7 @@ def test_async_sweeps_are_never_worse_than_synchronous_ones_64(interleave):
             assert worst < last
             last = worst
     finally:
-        capi.set_tuning("interleave=0")
+        capi.set_tuning("interleave=1")  # the default
     p.close()
 
 

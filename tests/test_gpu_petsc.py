@@ -113,6 +113,33 @@ def test_pcshell_pinned_value_array(tmp_path):
     assert np.array_equal(plain["z"], pinned["z"]) and np.array_equal(plain["z2"], pinned["z2"])
 
 
+def test_pcshell_sweep_mode_option_and_notice(tmp_path):
+    """-blasted_sweep_mode (not a reference option) chooses how ilu0 / sgs apply their sweeps; the default is the
+    reference's chaotic sweeps, and setup_blasted_stack says so when the outermost KSP is a method that assumes a
+    fixed preconditioner (PETSc's default gmres).  `deterministic` = synchronous sweeps: the oracle's, to 1e-12."""
+    m = matrix("baij")
+    r = W.rhs_vector(m["nbrows"] * 4)
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
+    _, _, res = run(tmp_path, opts)
+    assert "NOTE: -ksp_type gmres assumes a fixed preconditioner" in res.stdout
+    _, _, res = run(tmp_path, opts + ["-ksp_type", "fgmres"])
+    assert "NOTE:" not in res.stdout
+    _, _, res = run(tmp_path, ["-blasted_pc_type", "seqilu0", "-blasted_async_sweeps", "1,1"] + ASYNC_OPTS)
+    assert "NOTE:" not in res.stdout   # exact passes: a fixed operator
+    _, vecs, res = run(tmp_path, opts + ["-blasted_sweep_mode", "deterministic"])
+    assert "NOTE:" not in res.stdout
+    # (the factorisation sweeps stay asynchronous in this mode: build far past the fixed point, compare the apply)
+    fexact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    _, vecs, _ = run(tmp_path, ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,3"] + ASYNC_OPTS +
+                     ["-blasted_sweep_mode", "deterministic"])
+    assert rel(vecs["z"], O.ilu0_apply(m, fexact, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)) < 1e-10
+    _, vecs, _ = run(tmp_path, ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,3"] + ASYNC_OPTS +
+                     ["-blasted_sweep_mode", "exact"])
+    assert rel(vecs["z"], O.ilu0_apply(m, fexact, r, 1, mode=O.GS_SERIAL)) < 1e-10
+    _, _, res = run(tmp_path, opts + ["-blasted_sweep_mode", "bogus"], expect_rc=3)
+    assert "sweep mode must be" in res.stderr
+
+
 def test_pcshell_ilu0_scaled_with_info(tmp_path):
     """symmetric scaling and -blasted_compute_preconditioner_info: one PrecInfo per compute(), remainder
     below the initial remainder, values as the oracle's."""

@@ -71,6 +71,8 @@ PETSC_RUNS = [
      ("bjacobi", "shell"), []),
     (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3", "-blasted_compute_preconditioner_info", "1"], "baij",
      "seq", ("bjacobi", "shell"), []),
+    (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3", "-blasted_sweep_mode", "deterministic", "-ksp_type", "fgmres"],
+     "baij", "seq", ("bjacobi", "shell"), []),
     (["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "2,2"], "baij", "seq", ("bjacobi", "shell"),
      ["--b_file", os.path.join(G, "2dcyl1_b.pmat"), "--x_file", os.path.join(G, "2dcyl1_x.pmat"), "--max_iter", "5"]),
 ]
