@@ -96,9 +96,29 @@ __device__ __forceinline__ void sc_store(char *p, const double v)
 // asymptotic contraction (0.439 against 0.445: the slow error modes sit in the couplings between waves, not inside
 // them), and the seven dependent permute-and-reduce rounds cost 21 % on the lower and 81 % on the upper sweep:
 // profiles/r03_sweep_order_quality.txt.  The interleaved row order below does better for 12 %.)
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false, bool LR = false>
+// IW ("interleaved, with the wave's registers", round 3; bs = 4, one slot per row, one step in flight, triangular
+// sweeps): the interleaved row order -- lane group g of wave w takes rows 4g, 4g+1, 4g+2, 4g+3 of the wave's 32-row
+// window in its four steps -- with two of its memory round trips taken out:
+//  * the window's right-hand side (32 rows x 32 bytes = 1 KiB) is ONE coalesced 16-byte-per-lane load at the start
+//    of the chunk, handed to the step that needs it by a lane permute inside the 8-lane group, instead of a 32-byte
+//    piece per row and step, 128 bytes apart;
+//  * the coupling the interleaved order exists for -- a group's next row needs the row the group has JUST finished
+//    (its predecessor in a lower sweep, its successor in an upper one) -- is served from the group's registers: in an
+//    in-place sweep the gathered x segment of the block whose column is that row is replaced by the new result, so
+//    the freshness of that value no longer depends on the store having reached the caches.
+// Results are still stored step by step: collecting a window's results and storing it once, coalesced (built and
+// measured), makes the sweep as fast as the natural order (+2.5 % instead of +10 %) but delays what OTHER workgroups
+// see by up to three steps -- the row one grid line back belongs to the workgroup two chunks earlier, which in the
+// step-by-step form has usually stored it in time -- and the contraction per sweep falls back from 0.30 to 0.41
+// (natural order: 0.445): 52 ms instead of 43 ms to 1e-6 at 256^3.  Synchronous (double-buffered) sweeps use the
+// window but never the forwarding: they stay Jacobi sweeps, bit-identical in every row order.
+// 256^3 bs=4, lower + upper sweep: natural order 3.14 ms, this 3.45 ms, the round-1 form through memory 3.56 ms.
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false, bool LR = false,
+          bool IW = false>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
+	static_assert(!IW || (BS == 4 && UNR == 1 && NBV == 1 && !SC && (PART == PART_LOWER || PART == PART_UPPER)),
+	              "register-carried interleave: bs 4, triangular sweeps, one slot per row, one step in flight");
 
 	using Ge = WGeo<BS, NBV>;
 	constexpr int HB = Ge::HB, LPB = Ge::LPB, NB = Ge::NB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
@@ -160,6 +180,21 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	// that visit the whole row (SpMV, relaxation) get twice as many
 	constexpr int KFIX = (4 / NB) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);
 
+	// IW: this lane's 16-byte piece of the wave's window -- row (lane / 2) of the window, half (lane % 2)
+	constexpr int NSTEPS_W = RCHUNK / RSTEP;
+	static_assert(!IW || NSTEPS_W * HB == G, "a lane group's pieces of the window must be its own lanes");
+	double2_t win_r;
+	win_r.x = win_r.y = 0.0;
+	const bool inplace = a.xin == a.xout;
+	double prev0 = 0.0, prev1 = 0.0;  // the group's result of the step before (rows 2h, 2h+1)
+	if (IW) {
+		const int wls = (wave * RPW + g) * NSTEPS_W + (q >> 1);  // sweep position of this lane's piece
+		const bool win_ok = wls < rc;
+		const int win_lr = win_ok ? (descending ? rc - 1 - wls : wls) : 0;
+		if (win_ok && a.rhs)
+			win_r = *reinterpret_cast<const double2_t *>(rbase + ((unsigned)win_lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q & 1)));
+	}
+
 	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
 		int lrow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
 		bool ok[UNR];
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			// the same step (stale): the in-place sweep is Gauss-Seidel-like along the chunk, not Jacobi-like.
 			constexpr int NSTEPS = RCHUNK / RSTEP;
 			const int slotpos = wave * RPW + g;
-			const int ls = a.interleave ? slotpos * NSTEPS + (step0 + u) : (step0 + u) * RSTEP + slotpos;
+			const int ls = (IW || a.interleave) ? slotpos * NSTEPS + (step0 + u) : (step0 + u) * RSTEP + slotpos;
 			ok[u] = ls < rc;
 			const int lr = ok[u] ? (descending ? rc - 1 - ls : ls) : 0;
 			lrow[u] = lr;
@@ -202,6 +237,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 		constexpr int NXG = XG ? KFIX / 4 : 1;
 		double2_t xg[UNR][NXG];
 		constexpr bool xg_on = XG;
+		int colmine = -1;  // IW: the column of the pass this lane gathers for (pass q % 4)
 		if (xg_on) {
 #pragma unroll
 			for (int u = 0; u < UNR; u++) {
@@ -214,6 +250,8 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 					if (PART != PART_NONE && jj < jend[u] && !skip) {
 						const int cidx = jj - jlo;
 						const int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
+						if (IW && kg == 0)
+							colmine = col;
 						const char *const xp = xbase + ((unsigned)col * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q >> 2));
 						if (SC) {
 							xg[u][kg].x = sc_load(xp);
@@ -260,7 +298,15 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				    dbase + ((unsigned)lrow[u] * (unsigned)Ge::BLKBYTES + 16u * (unsigned)q)));
 			r2[u].x = r2[u].y = 0.0;
 			s2[u].x = s2[u].y = 1.0;
-			if (ok[u] && a.rhs) {
+			if (IW) {
+				// this step's row of the window: pieces 2 * step, 2 * step + 1 of the lane group
+				const int src = (lane & ~(G - 1)) | (2 * (step0 + u)) | (q & 1);
+				r2[u].x = __shfl(win_r.x, src, 64);
+				r2[u].y = __shfl(win_r.y, src, 64);
+				if (ok[u] && a.rhs && a.rscale)
+					s2[u] = *reinterpret_cast<const double2_t *>(
+					    sbase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
+			} else if (ok[u] && a.rhs) {
 				r2[u] = *reinterpret_cast<const double2_t *>(
 				    rbase + ((unsigned)lrow[u] * (unsigned)Ge::ROWBYTES + 16u * (unsigned)h));
 				if (a.rscale)
@@ -280,6 +326,25 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 						// component c of the segment of pass k: held by lane k%4 of this lane's quad (c/2 = quad)
 						const double gx = quad_bcast(xg[u][k / 4].x, k & 3), gy = quad_bcast(xg[u][k / 4].y, k & 3);
 						xv[u][k] = (c & 1) ? gy : gx;
+					}
+					if (IW && inplace && step0 + u > 0) {
+						// the row this group finished in the step before: its new segment, from the group's registers
+						const int prow = r0 + lrow[u] + (descending ? 1 : -1);
+						const int mine = (colmine == prow) ? 1 : 0;
+						const double a00 = dpp_mov<0x00>(prev0), a01 = dpp_mov<0x00>(prev1);  // quad_perm [0,0,0,0]
+						const double a10 = dpp_mov<0x55>(prev0), a11 = dpp_mov<0x55>(prev1);  // quad_perm [1,1,1,1]
+						const bool b1 = (q & 2) != 0, b2 = (q & 4) != 0;
+						const double f0 = b2 ? a10 : a00, f1 = b2 ? a11 : a01;
+						const double fresh = b1 ? f1 : f0;  // component c of the previous row's result
+#pragma unroll
+						for (int k = 0; k < KFIX && k < 4; k++) {
+							// pass k was gathered by lane k of every quad: is its column the previous row?
+							const int hit = k == 0 ? __builtin_amdgcn_update_dpp(0, mine, 0x00, 0xf, 0xf, false)
+							              : k == 1 ? __builtin_amdgcn_update_dpp(0, mine, 0x55, 0xf, 0xf, false)
+							              : k == 2 ? __builtin_amdgcn_update_dpp(0, mine, 0xAA, 0xf, 0xf, false)
+							                       : __builtin_amdgcn_update_dpp(0, mine, 0xFF, 0xf, 0xf, false);
+							xv[u][k] = hit ? fresh : xv[u][k];
+						}
 					}
 				}
 #pragma unroll
@@ -385,6 +450,10 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			};
 			post_op(acc0, acc1);
 
+			if (IW) {
+				prev0 = o0;
+				prev1 = o1;
+			}
 			if (ok[u] && slot == 0 && q < HB) {
 				double2_t o2;
 				o2.x = o0;
@@ -470,8 +539,14 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 			constexpr int KSTRAIGHT = (4 / 1) * ((PART == PART_ALL || PART == PART_OFFDIAG) ? 2 : 1);      \
 			const bool whole = PART == PART_ALL || PART == PART_OFFDIAG;                                   \
 			const int longest_part = whole ? a.pat.max_row_len : (a.pat.max_row_len + 1) / 2 + 1;          \
+			/* interleaved row order through the wave's registers (IW, see the kernel); "interleave=2" keeps the  \
+			   round-1 form that goes through memory */                                                     \
+			constexpr bool IWOK = BS == 4 && RV == 128 && UV == 1 && (PART == PART_LOWER || PART == PART_UPPER); \
 			if (longest_part > KSTRAIGHT + 1 && UN1 == 1)                                                  \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, true>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else if (IWOK && a.interleave == 1)                                                            \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, IWOK>), \
 				                   dim3(grid), dim3(256), 0, s, a);                                        \
 			else                                                                                           \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), UN1, 1>), dim3(grid), \
