@@ -587,8 +587,13 @@ static bool launch_bs(const SweepArgs &a, Part part, Post post, DSrc dsrc, const
 }
 
 // returns false when the tuned kernel does not cover the request (caller uses the generic family)
-bool launch_sweepw(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
+bool launch_sweepw(const SweepArgs &a_, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
+	SweepArgs a = a_;
+	// the interleaved row order is for in-place TRIANGULAR sweeps (where a fresher predecessor is worth its price,
+	// profiles/r03_sweep_order_quality.txt); products, synchronous sweeps and relaxation passes keep the natural order
+	if (a.xin != a.xout || !(part == PART_LOWER || part == PART_UPPER))
+		a.interleave = 0;
 	const Variant &v = current_variant();
 	const int bs = a.pat.bs;
 	if (!v.enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || a.pat.nbrows == 0)

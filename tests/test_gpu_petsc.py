@@ -176,34 +176,35 @@ def test_pcshell_sgs_apply_and_richardson(tmp_path, mat_type, vec_type):
     assert rel(vecs["x"], O.sgs_relax(m, d, r, maxits=4, mode=O.JACOBI_SYNC)) < 1e-11
 
 
-@pytest.mark.parametrize("sweep_mode", [None, "async"])
+@pytest.mark.parametrize("sweep_mode", [None, "async", "deterministic"])
 def test_pcshell_sgs_product_modes_forward_half_exact(tmp_path, sweep_mode):
-    """the reference's low sweep count in the two product modes.  Default (deterministic): exact forward half,
-    then synchronous backward sweeps -- equal to the oracle's composition of the two.  BLASTED_HIP_SWEEP_MODE=
-    async (the reference's chaotic sweeps): z is no farther from the exact SGS application than that (Q3)."""
+    """the reference's low sweep count in the product modes.  Deterministic: exact forward half, then synchronous
+    backward sweeps -- equal to the oracle's composition of the two.  Async (the default: the reference's chaotic
+    sweeps): z is no farther from the exact SGS application than that (Q3)."""
     m = matrix("baij")
     env = {"BLASTED_HIP_SWEEP_MODE": sweep_mode} if sweep_mode else None
+    fixed = sweep_mode == "deterministic"
     rep, vecs, _ = run(tmp_path, ["-blasted_pc_type", "sgs", "-blasted_async_sweeps", "1,2"] + ASYNC_OPTS, env=env)
-    check_common(rep, vecs, 4, homogeneous=sweep_mode is None)  # (chaotic sweeps are not reproducible to the last bit)
+    check_common(rep, vecs, 4, homogeneous=fixed)  # (chaotic sweeps are not reproducible to the last bit)
     r = W.rhs_vector(m["nbrows"] * 4)
     d = O.jacobi_compute(m)
     ze, ye = O.sgs_apply(m, d, r, 1, mode=O.GS_SERIAL, return_y=True)
     zj = O.sgs_apply(m, d, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_NONE, y0=ye, z0=np.zeros_like(r))
-    if sweep_mode is None:
+    if fixed:
         assert rel(vecs["z"], zj) < 1e-12
     else:
         assert np.linalg.norm(vecs["z"] - ze) <= 1.05 * np.linalg.norm(zj - ze) + 1e-12 * np.linalg.norm(ze)
 
 
-def test_pcshell_default_is_a_fixed_operator(tmp_path):
-    """two runs of the default mode give bit-identical applications (what a non-flexible Krylov method needs),
+def test_pcshell_deterministic_mode_is_a_fixed_operator(tmp_path):
+    """two runs with synchronous sweeps give bit-identical applications (what a non-flexible Krylov method needs),
     and BLASTED_HIP_SWEEP_MODE is validated"""
     opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
     _, v1, _ = run(tmp_path, opts, env=SYNC)   # synchronous factorisation as well: everything deterministic
     _, v2, _ = run(tmp_path, opts, env=SYNC)
     assert np.array_equal(v1["z"], v2["z"])
     _, _, r = run(tmp_path, opts, env={"BLASTED_HIP_SWEEP_MODE": "bogus"}, expect_rc=3)
-    assert "BLASTED_HIP_SWEEP_MODE" in r.stderr
+    assert "sweep mode must be" in r.stderr
 
 
 @pytest.mark.parametrize("opts,kind", [
