@@ -564,7 +564,14 @@ def main():
                 p.set_timing(False)
                 fms = tf_["lower_ms"] / max(tf_["lower_launches"], 1)
                 tb = ab["factor_sweep_touched"]
-                out["factor"] = {"async_factor_ms": asf, "nbuildsweeps": cfg["build"], "sweep_ms": fms,
+                ftraffic = None
+                try:
+                    fent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("factor", {}) if args.config == 2 and not custom else {}
+                    ftraffic = {"hbm_bytes_per_launch": fent.get("hbm_bytes_per_launch"), "profiles": fent.get("from"),
+                                "commit": fent.get("commit")} if fent else None
+                except Exception:
+                    ftraffic = None
+                out["factor"] = {"async_factor_ms": asf, "nbuildsweeps": cfg["build"], "sweep_ms": fms, "traffic": ftraffic,
                                  "algorithmic_bytes_per_sweep": ab["factor_sweep"],
                                  "touched_bytes_per_sweep": tb, "fixed_upper_blocks": ab["fixed_upper"],
                                  "achieved": tb / (fms * 1e-3) / 1e9 if fms > 0 else 0.0,

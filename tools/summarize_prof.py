@@ -21,7 +21,9 @@ def one(pattern):
 # bench config number -> (key in profiles/traffic.json = the workload name, name fragments of its dominant kernel)
 CONFIG_KERNELS = {
     "1": ("poisson3d_64_csr_async_ilu0_apply", ("sweep_kernel<1, false, 1,",)),
-    "2": ("ilu_apply", ("sweepw_kernel<4, 1,", "sweep_kernel<")),
+    # (the default row order of the in-place bs=4 triangular sweeps is the interleaved one: the IW instantiation, last
+    # template argument true; bench.py also times the natural order beside it)
+    "2": ("ilu_apply", ("sweepw_kernel<4, 1, 1, 1, 128, true, 1, 1, false, false, true>", "sweepw_kernel<4, 1,", "sweep_kernel<")),
     "3": ("poisson3d_256_bs4_async_block_sgs_relaxation", ("sweepw_kernel<4, 2,",)),
     "4": ("unstructured_126_bs5_async_block_ilu0_apply", ("sweepodd_kernel<5, 1,", "sweepx_kernel<5, 1,")),
     "5": ("poisson3d_100_bs8_block_ilu0_apply", ("sweepw_kernel<8, 1,",)),
@@ -92,9 +94,35 @@ def main(tag, op="ilu_apply"):
             break
     tf = os.path.join(prof, "traffic.json")
     cur = json.load(open(tf)) if os.path.exists(tf) else {}
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+
+    def entry(k):
+        return {"kernel": k, "hbm_bytes_per_launch": pmc[k]["hbm_bytes_per_launch"], "from": tag, "commit": commit,
+                "launches_in_fetch_pass": pmc[k].get("launches_FETCH_SIZE")}
     if dom:
-        cur[op] = {"kernel": dom[0], "hbm_bytes_per_launch": pmc[dom[0]]["hbm_bytes_per_launch"], "from": tag}
-        json.dump(cur, open(tf, "w"), indent=1)
+        cur[op] = entry(dom[0])
+    # side kernels of the default configuration's run: the factorisation sweep and the exact (level-scheduled) passes
+    extras = {"factor": ("factor4_kernel",), "ilu_apply_natural_order": ("sweepw_kernel<4, 1, 1, 1, 128, true, 1, 1, false, false, false>",),
+              "exact_lower_pass": ("sfw_kernel<4, false",), "exact_upper_pass": ("sfw_kernel<4, true",),
+              "lower_sweep": ("sweepw_kernel<4, 0, 0, 0, 128, true, 1, 1, false, false, true>",)}
+    if op == "ilu_apply":
+        for name, frags in extras.items():
+            ks = sorted([k for k in pmc if any(f in k for f in frags) and "hbm_bytes_per_launch" in pmc[k]],
+                        key=lambda k: -pmc[k]["launches_FETCH_SIZE"])
+            if ks:
+                cur[name] = entry(ks[0])
+        ex = {k: v for k, v in pmc.items() if "sfw_kernel" in k or "sf_fill_kernel" in k or "sf_sweep_kernel" in k}
+        if ex:
+            json.dump(ex, open(os.path.join(prof, "%s_exact_solve_pmc.json" % tag.split("_c")[0]), "w"), indent=1)
+            if stats:
+                keep = [rows[0]] + [r for r in rows[1:] if "sfw_kernel" in r[0] or "sf_fill_kernel" in r[0] or "sf_sweep_kernel" in r[0]]
+                with open(os.path.join(prof, "%s_exact_solve_kernel_stats.csv" % tag.split("_c")[0]), "w", newline="") as f:
+                    csv.writer(f).writerows(keep)
+    json.dump(cur, open(tf, "w"), indent=1)
     print(json.dumps(pmc, indent=1)[:6000])
 
 
