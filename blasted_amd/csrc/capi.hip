@@ -1743,7 +1743,7 @@ int blasted_hip_set_tuning(const char *spec)
 		if (spec && std::strncmp(spec, "levelperm=", 10) == 0)
 			g_level_perm = spec[10] != '0';
 		else if (spec && std::strncmp(spec, "interleave=", 11) == 0)
-			g_interleave = spec[11] == '0' ? 0 : (spec[11] == '2' ? 2 : 1);  // 2: the round-1 form (through memory)
+			g_interleave = spec[11] == '0' ? 0 : (spec[11] == '2' ? 2 : (spec[11] == '3' ? 3 : 1));  // 2: the round-1 form (through memory); 3: that form for relaxation passes too
 		else if (spec && std::strncmp(spec, "compact=", 8) == 0)
 			g_compact = spec[8] != '0';
 		else if (spec && std::strncmp(spec, "sfonestep=", 10) == 0)

@@ -592,8 +592,11 @@ bool launch_sweepw(const SweepArgs &a_, Part part, Post post, DSrc dsrc, hipStre
 	SweepArgs a = a_;
 	// the interleaved row order is for in-place TRIANGULAR sweeps (where a fresher predecessor is worth its price,
 	// profiles/r03_sweep_order_quality.txt); products, synchronous sweeps and relaxation passes keep the natural order
-	if (a.xin != a.xout || !(part == PART_LOWER || part == PART_UPPER))
+	// ("interleave=3", measurements: every in-place pass, relaxation included, in the through-memory form)
+	if (a.xin != a.xout || (!(part == PART_LOWER || part == PART_UPPER) && a.interleave != 3))
 		a.interleave = 0;
+	if (a.interleave == 3)
+		a.interleave = 2;
 	const Variant &v = current_variant();
 	const int bs = a.pat.bs;
 	if (!v.enabled || (bs != 4 && bs != 8) || a.pat.rowmajor || a.pat.nbrows == 0)
