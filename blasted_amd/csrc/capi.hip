@@ -1751,7 +1751,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
 		else if (spec && std::strncmp(spec, "gatherprobe=", 12) == 0)
-			g_gather_probe = spec[12] != '0';  // measurements only: wrong results
+			g_gather_probe = spec[12] - '0';  // measurements only: wrong results (1: sweepodd gathers its own row; 2, 3: store probes of the interleaved bs=4 sweeps)
 		else if (spec && std::strncmp(spec, "levelnowait=", 12) == 0)
 			set_syncfree_nowait(spec[12] - '0');  // measurements only: wrong results
 		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)
