@@ -780,6 +780,72 @@ def test_async_sweeps_are_never_worse_than_synchronous_ones_64(interleave):
     p.close()
 
 
+def test_interleaved_sweep_forwards_the_finished_row_in_registers():
+    """The interleaved row order with the wave's registers (kernels_sweepw.hip, IW), pinned deterministically: on 32
+    block-rows ONE wave owns the whole sweep -- lane group g takes rows 4g .. 4g+3 in its four steps -- so an in-place
+    sweep is a fixed sequence: a row sees the NEW value of the neighbour its own lanes finished in the step before
+    (rows 4g+1, 4g+2, 4g+3 in an ascending sweep) and the old one otherwise (rows 4g: their predecessor belongs to the
+    next lane group's last step).  Block-tridiagonal bs = 4 matrix, SGS application with asynchronous forward and
+    backward sweeps (one each, from zero): y and z against that sequence evaluated in numpy."""
+    rng = np.random.default_rng(5)
+    nb, bs = 32, 4
+    rp = [0]
+    ci = []
+    for i in range(nb):
+        ci += [j for j in (i - 1, i, i + 1) if 0 <= j < nb]
+        rp.append(len(ci))
+    ci = np.array(ci, dtype=np.int32)
+    rp = np.array(rp, dtype=np.int32)
+    rowof = np.repeat(np.arange(nb), rp[1:] - rp[:-1])
+    blocks = rng.uniform(-0.5, 0.5, (ci.size, bs, bs))          # [block][r][c]
+    blocks[ci == rowof] += 3.0 * np.eye(bs)
+    dg = np.array([int(np.where((rowof == i) & (ci == i))[0][0]) for i in range(nb)], dtype=np.int32)
+    m = dict(nbrows=nb, nnzb=int(ci.size), bs=bs, rowmajor=False, browptr=rp, bcolind=ci, diagind=dg,
+             vals=np.ascontiguousarray(np.transpose(blocks, (0, 2, 1))).reshape(-1))   # column-major blocks
+    r = W.rhs_vector(nb * bs).reshape(nb, bs)
+    Dinv = [np.linalg.inv(blocks[dg[i]]) for i in range(nb)]
+    blk = {(int(rowof[k]), int(ci[k])): blocks[k] for k in range(ci.size)}
+    # forward sweep, ascending, from y = 0: step s takes rows 4g + s
+    y = np.zeros((nb, bs))
+    for step in range(4):
+        new = {}
+        for g in range(8):
+            i = 4 * g + step
+            acc = blk[(i, i - 1)] @ y[i - 1] if i > 0 else np.zeros(bs)   # y[i-1]: new iff step > 0 (same lane group)
+            new[i] = Dinv[i] @ (r[i] - acc)
+        for i, v in new.items():
+            y[i] = v
+    # backward sweep, descending, from z = 0: step s takes rows 31 - 4g - s
+    z = np.zeros((nb, bs))
+    for step in range(4):
+        new = {}
+        for g in range(8):
+            i = nb - 1 - (4 * g + step)
+            acc = blk[(i, i + 1)] @ z[i + 1] if i + 1 < nb else np.zeros(bs)
+            new[i] = y[i] - Dinv[i] @ acc
+        for i, v in new.items():
+            z[i] = v
+    p = make_prec(m)
+    p.jacobi_compute()
+    capi.set_tuning("sgsfwd=async")
+    capi.set_tuning("interleave=1")
+    try:
+        got_z = p.sgs_apply(r.reshape(-1), 1, init=capi.INIT_A_ZERO, mode=capi.ASYNC)
+        got_y = p.get_ytemp()
+        # the natural order is NOT this sequence (rows 0..7 of a step are Jacobi among themselves, four waves race)
+        capi.set_tuning("interleave=0")
+        nat_y = None
+        p.sgs_apply(r.reshape(-1), 1, init=capi.INIT_A_ZERO, mode=capi.ASYNC)
+        nat_y = p.get_ytemp()
+    finally:
+        capi.set_tuning("sgsfwd=exact")
+        capi.set_tuning("interleave=1")
+    assert rel(got_y, y.reshape(-1)) < 1e-13
+    assert rel(got_z, z.reshape(-1)) < 1e-13
+    assert rel(nat_y, y.reshape(-1)) > 1e-6
+    p.close()
+
+
 def test_config0_scalar_poisson_64_chebyshev():
     """BASELINE config 0: tests/poisson3d-fd 64^3 scalar CSR on the reference's default Chebyshev grid
     (input/poisson.control), async ILU(0) with 3 build and 3 apply sweeps."""
