@@ -485,7 +485,7 @@ def main():
                        "generator": cfg["gen"], "grid_points": n, "block_size": bs, "nbrows": ab["nbrows"],
                        "nnzb": ab["nnzb"], "nnz_lower": ab["nnzl"], "nnz_upper": ab["nnzu"],
                        "napplysweeps": s, "nbuildsweeps": cfg["build"], "sweep_mode": "async",
-                       "row_order_in_chunk": "interleaved (default)" if bs in (4, 8) else "natural", "grid": cfg["grid"],
+                       "row_order_in_chunk": "natural (default)", "grid": cfg["grid"],
                        "replicas": world,
                        "unit_definition": "one %s = %d algorithmic bytes" % (
                            {"ilu_apply": "L+U sweep pair",
@@ -594,24 +594,29 @@ def main():
                                                      "HipOperator::sweep_mode) is the mode this line measures"}
                 out["quality"] = quality_figures(p, capi, torch, r, z, s)
                 if bs in (4, 8):
-                    # the row order inside a chunk is chosen by what a sweep is worth per millisecond (interleaved, the
-                    # default): the natural order -- faster per sweep, weaker per sweep -- measured beside it
+                    # the other row order inside a chunk, measured beside the default: interleaved (a row's predecessor
+                    # belongs to the step before) -- closer to the exact solves per sweep, 10 % dearer per sweep, and no
+                    # better inside the reference's flexible solver (profiles/r03_sweep_order_quality.txt), hence not
+                    # the default
                     try:
-                        capi.set_tuning("interleave=0")
+                        capi.set_tuning("interleave=1")
                         p.set_timing(True)
                         p.get_timing(reset=True)
                         alt_ms = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z))
                         ta = p.get_timing(reset=True)
                         p.set_timing(False)
                         ums = ta["upper_ms"] / max(ta["upper_launches"], 1)
-                        alt = {"tuning": "interleave=0 (rows of a step consecutive)", "ms_per_step": alt_ms,
-                               "value": s / (alt_ms * 1e-3), "unit": "sweeps/s",
+                        alt = {"tuning": "interleave=1 (rows of a step four apart, the finished row forwarded in registers)",
+                               "ms_per_step": alt_ms, "value": s / (alt_ms * 1e-3), "unit": "sweeps/s",
                                "lower_ms": ta["lower_ms"] / max(ta["lower_launches"], 1), "upper_ms": ums,
-                               "upper_frac": ab["upper_sweep"] / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS if ums > 0 else 0.0}
+                               "upper_frac": ab["upper_sweep"] / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS if ums > 0 else 0.0,
+                               "gcr_iterations_160": {"natural, 3 / 5 sweeps": "943-960 / 516-517",
+                                                      "interleaved, 3 / 5 sweeps": "1173-1196 / 510-511",
+                                                      "source": "profiles/r03_sweep_order_quality.txt"}}
                         alt.update(quality_figures(p, capi, torch, r, z, s))
                         out["sweep_order_alternative"] = alt
                     finally:
-                        capi.set_tuning("interleave=1")
+                        capi.set_tuning("interleave=0")
                 if cfg["gen"] != "unstructured" and not args.no_cpu_baseline:
                     try:
                         out["quality"]["same_matrix_reference"] = reference_side_quality(cfg, capi, workloads, torch, dev, s)

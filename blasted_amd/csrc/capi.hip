@@ -477,23 +477,28 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 	return launch_level_sweep(a, part, post, dsrc, ls, p->stream);
 }
 
-// "interleave=1" (default from round 3 on) / "interleave=0" (environment BLASTED_HIP_INTERLEAVE=0|1): the rows a
-// workgroup of the bs=4/8 column-major sweep computes side by side are taken a step count apart, so a row's
-// predecessor belongs to the previous step (already stored) instead of to the same step (stale): Gauss-Seidel-like
-// along a chunk, as the reference's threads are inside their chunks.  256^3 bs=4, distance to the exact solves after
-// 3+3 / 10+10 sweeps 0.161 / 5.6e-4 -> 0.063 / 1.6e-5: contraction per sweep 0.445 -> 0.305, i.e. 1.45x fewer sweeps
-// for the same accuracy, at +12 % time per sweep pair: 43 ms instead of 56 ms to bring the distance to 1e-6 (7.0
-// against 7.7 ms at 128^3; profiles/r03_sweep_order_quality.txt).  Rounds 1-2 kept it off because the headline
-// metric counts sweeps per second; the default is now chosen by what a sweep is worth as a preconditioner per
-// millisecond, and bench.py reports the natural row order beside it (`sweep_order_alternative`).
-// Where the +12..15 % comes from (round 1, tools/probes): the timing-only variant without gathers pays +16 % for the
-// 32-byte rhs / result pieces a step now takes 4 rows apart; storing the triangles in sweep order does not
+// "interleave=1" / "interleave=0" (default; environment BLASTED_HIP_INTERLEAVE=1|0): the rows a workgroup of the
+// bs=4/8 column-major in-place triangular sweeps computes side by side are taken a step count apart, so a row's
+// predecessor belongs to the previous step instead of to the same step (stale): Gauss-Seidel-like along a chunk, as the
+// reference's threads are inside their chunks.  Round 3 rebuilt it for bs = 4 (kernels_sweepw.hip, IW: right-hand
+// side window, the just-finished row forwarded in registers: +10 % per sweep pair instead of +13..15 %) and measured
+// it two ways (profiles/r03_sweep_order_quality.txt, 256^3 / 160^3 bs=4):
+//  * distance of z to the exact solves: after 3+3 / 10+10 sweeps 0.160 / 5.4e-4 -> 0.058 / 1.2e-5, contraction per
+//    sweep 0.445 -> 0.30: 41-43 ms instead of 56-59 ms to bring the distance to 1e-6;
+//  * time to solution inside the reference's flexible solver, GCR(30) at 160^3, three repetitions: 3 sweeps 943-960
+//    iterations in natural order against 1173-1196 interleaved, 5 sweeps 516-517 against 510-511 -- the interleaved
+//    sweeps leave a smaller but differently structured error (every fourth row still sees a stale predecessor), and
+//    as a preconditioner they are no better per application and 10 % dearer.
+// The default is decided by the second measurement: natural order.  "interleave=2" is the round-1 form that goes
+// through memory for everything, "interleave=3" applies that form to relaxation passes too (no gain measured).
+// Where the round-1 form's +13..15 % came from (tools/probes): the timing-only variant without gathers pays +16 %
+// for the 32-byte rhs / result pieces a step takes 4 rows apart; storing the triangles in sweep order does not
 // help (the value stream was not the problem); and sweeping the symmetrically permuted system, on which every
 // access is contiguous again, still pays +10 % per sweep pair -- fresh neighbours are lines another wave has
 // just written -- plus two vector permutation passes per application.  Both were built, measured and removed.
 static int g_interleave = [] {
 	const char *e = std::getenv("BLASTED_HIP_INTERLEAVE");
-	return (e && e[0] == '0') ? 0 : 1;
+	return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
 }();
 
 // tuning ("xcdsuper=N", N a power of two): the XCDs take turns on super-chunks of N consecutive chunks (lanes.hpp)

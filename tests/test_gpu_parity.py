@@ -776,7 +776,7 @@ def test_async_sweeps_are_never_worse_than_synchronous_ones_64(interleave):
             assert worst < last
             last = worst
     finally:
-        capi.set_tuning("interleave=1")  # the default
+        capi.set_tuning("interleave=0")  # the default
     p.close()
 
 
@@ -839,7 +839,7 @@ def test_interleaved_sweep_forwards_the_finished_row_in_registers():
         nat_y = p.get_ytemp()
     finally:
         capi.set_tuning("sgsfwd=exact")
-        capi.set_tuning("interleave=1")
+        capi.set_tuning("interleave=0")
     assert rel(got_y, y.reshape(-1)) < 1e-13
     assert rel(got_z, z.reshape(-1)) < 1e-13
     assert rel(nat_y, y.reshape(-1)) > 1e-6

@@ -139,7 +139,7 @@ def main():
             check("jacobi_relax", xj, O.jacobi_relax(m, d, r, x0=x0, maxits=2)[0], 1e-10)
         assert p.level_stats()["syncfree_aborts"] == 0, case
         p.close()
-    for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=1",
+    for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
                  "factor8=1", "gunroll=0", "copies=one", "xcdsuper=16", "levelserial=4096", "levelfast=1",
                  "factorsf=1", "factorsf=p1", "factorskip=1", "r128,nt1,u1,s1"):

@@ -38,7 +38,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) * 1e3
             print("%-14s %2d relaxation steps: %8.2f ms, relative residual %.3e" % (spec, k, dt, res), flush=True)
-    capi.set_tuning("interleave=1")
+    capi.set_tuning("interleave=0")
     p.close()
 
 
