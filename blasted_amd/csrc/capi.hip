@@ -518,6 +518,13 @@ static int g_sgs_exact_fwd = 1;
 
 static int g_gather_probe = 0;  // tuning "gatherprobe=1": see SweepArgs::probe
 
+// tuning "latestore=2" (default) / "latestore=0|1|4" (environment BLASTED_HIP_LATESTORE): the in-place bs=4 triangular
+// sweeps store a workgroup's rows once, with 2 (1, 4) row steps of a wave in flight; 0 = step by step (kernels_sweepw.hip, LS)
+static int g_late_store = [] {
+	const char *e = std::getenv("BLASTED_HIP_LATESTORE");
+	return (e && (e[0] == '0' || e[0] == '1' || e[0] == '4')) ? e[0] - '0' : 2;
+}();
+
 static SweepArgs base_args(blasted_hip_prec p)
 {
 	SweepArgs a;
@@ -525,6 +532,7 @@ static SweepArgs base_args(blasted_hip_prec p)
 	a.pat = p->pat;
 	a.interleave = g_interleave;
 	a.probe = g_gather_probe;
+	a.latestore = g_late_store;
 	a.xcd_shift = g_xcd_shift;
 	a.a = 1.0;
 	a.b = 0.0;
@@ -1755,6 +1763,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "latestore=", 10) == 0)
+			g_late_store = (spec[10] == '0' || spec[10] == '1' || spec[10] == '2' || spec[10] == '4') ? spec[10] - '0' : 2;  // row steps in flight; 0: stores step by step
 		else if (spec && std::strncmp(spec, "gatherprobe=", 12) == 0)
 			g_gather_probe = spec[12] - '0';  // measurements only: wrong results (1: sweepodd gathers its own row; 2, 3: store probes of the interleaved bs=4 sweeps)
 		else if (spec && std::strncmp(spec, "levelnowait=", 12) == 0)

@@ -70,6 +70,7 @@ struct SweepArgs {
 	int descending;         // row order of the sweep
 	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp), default 4
 	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
+	int latestore;          // in-place bs=4 triangular sweeps in natural order store a chunk's results once (kernels_sweepw.hip, LS)
 	int probe;              // measurements only (tuning "gatherprobe=1", WRONG results): kernels_sweepodd.hip gathers
 	                        // every block's x segment from the row's OWN position -- the sweep at its algorithmic traffic
 };

@@ -114,9 +114,26 @@ __device__ __forceinline__ void sc_store(char *p, const double v)
 // window but never the forwarding: they stay Jacobi sweeps, bit-identical in every row order.
 // 256^3 bs=4, lower + upper sweep: natural order 3.14 ms, this 3.45 ms, the round-1 form through memory 3.56 ms.
 template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT, int UNR, int NBV, bool SC = false, bool LR = false,
-          bool IW = false>
+          bool IW = false, bool LS = false>
 __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 {
+	// LS ("late store", round 3; default -- with two row steps in flight -- for the in-place bs = 4 triangular sweeps
+	// in natural row order): the results of a lane group's steps are collected in registers and a workgroup's 128
+	// rows are stored once, after its last step (16 bytes per lane, 256-byte runs), instead of 32 bytes per row and
+	// step.  Other workgroups see a chunk's rows up to three steps later: the sweep is MORE Jacobi-like -- distance to the
+	// exact solves after 3+3 / 10+10 sweeps 0.24 / 2.6e-3 instead of 0.16 / 5.5e-4 at 256^3 -- and a BETTER
+	// preconditioner, because what it does depends less on which wave won which race.  Measured on Poisson (x) 4x4 block,
+	// 160^3 (profiles/r03_sweep_order_quality.txt): difference between two applications to the same vector / GCR(30)
+	// iterations at 3 and 5 sweeps / time of a 256^3 lower + upper sweep --
+	//     stores step by step, one step in flight (rounds 1-2)   2.2-2.5e-2   943-981 / 516-520   3.03 ms
+	//     late store, one step in flight  ("latestore=1")        1.7e-2       798-802 / 512-517   3.03 ms
+	//     late store, two steps in flight ("latestore=2", DEFAULT) 8.8e-3     684     / 498       2.98 ms
+	//     late store, four steps in flight ("latestore=4")       8.9e-4       656     / 491       3.24 ms
+	//     interleaved order ("interleave=1")                     2.3e-2       1173-1196 / 510     3.32-3.45 ms
+	//     synchronous sweeps (mode DETERMINISTIC)                0            655     / -         (2 of 3 sweeps read the matrix)
+	// i.e. among in-place sweeps on this GPU the more repeatable operator is the better one, down to the synchronous
+	// sweeps' iteration count, and two steps in flight with a late store is also the fastest form.
+	static_assert(!LS || (BS == 4 && (UNR == 1 || UNR == 2 || UNR == 4) && NBV == 1 && !SC && !IW && (PART == PART_LOWER || PART == PART_UPPER)), "late store");
 	static_assert(!IW || (BS == 4 && UNR == 1 && NBV == 1 && !SC && (PART == PART_LOWER || PART == PART_UPPER)),
 	              "register-carried interleave: bs 4, triangular sweeps, one slot per row, one step in flight");
 
@@ -185,6 +202,8 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	static_assert(!IW || NSTEPS_W * HB == G, "a lane group's pieces of the window must be its own lanes");
 	double2_t win_r;
 	win_r.x = win_r.y = 0.0;
+	double2_t late_o;
+	late_o.x = late_o.y = 0.0;
 	const bool inplace = a.xin == a.xout;
 	double prev0 = 0.0, prev1 = 0.0;  // the group's result of the step before (rows 2h, 2h+1)
 	if (IW) {
@@ -195,6 +214,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 			win_r = *reinterpret_cast<const double2_t *>(rbase + ((unsigned)win_lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q & 1)));
 	}
 
+#pragma unroll 1
 	for (int step0 = 0; step0 < RCHUNK / RSTEP; step0 += UNR) {
 		int lrow[UNR], jbeg[UNR], jend[UNR], dgp[UNR];
 		bool ok[UNR];
@@ -454,7 +474,12 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				prev0 = o0;
 				prev1 = o1;
 			}
-			if (ok[u] && slot == 0 && q < HB) {
+			if (LS) {
+				if ((q >> 1) == step0 + u) {  // lane (g, q) keeps the result of step q / 2, half q % 2 = h
+					late_o.x = o0;
+					late_o.y = o1;
+				}
+			} else if (ok[u] && slot == 0 && q < HB) {
 				double2_t o2;
 				o2.x = o0;
 				o2.y = o1;
@@ -471,6 +496,13 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				else
 					*reinterpret_cast<double2_t *>(dst) = o2;
 			}
+		}
+	}
+	if (LS) {
+		const int ls = (q >> 1) * RSTEP + wave * RPW + g;
+		if (ls < rc) {
+			const int lr = descending ? rc - 1 - ls : ls;
+			*reinterpret_cast<double2_t *>(obase + ((unsigned)lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q & 1))) = late_o;
 		}
 	}
 }
@@ -550,6 +582,15 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 			constexpr bool IWOK = BS == 4 && RV == 128 && UV == 1 && (PART == PART_LOWER || PART == PART_UPPER); \
 			if (longest_part > KSTRAIGHT + 1 && UN1 == 1)                                                  \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, true>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else if (IWOK && a.latestore == 2 && !a.interleave && a.xin == a.xout)                         \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), (IWOK ? 2 : 1), 1, false, false, false, IWOK>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else if (IWOK && a.latestore == 4 && !a.interleave && a.xin == a.xout)                         \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), (IWOK ? 4 : 1), 1, false, false, false, IWOK>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else if (IWOK && a.latestore && !a.interleave && a.xin == a.xout)                              \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, false, IWOK>), \
 				                   dim3(grid), dim3(256), 0, s, a);                                        \
 			else if (IWOK && a.interleave == 1)                                                            \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, IWOK>), \
