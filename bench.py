@@ -593,6 +593,11 @@ def main():
                                              "note": "the host C++ layer's default sweep mode (operators.cpp, "
                                                      "HipOperator::sweep_mode) is the mode this line measures"}
                 out["quality"] = quality_figures(p, capi, torch, r, z, s)
+                out["quality"]["note"] = ("distance of z to the exact solves: a yardstick, not the goal -- in the reference's "
+                                          "flexible solver the sweep variants rank by how REPEATABLE they are, the other way "
+                                          "round (GCR(30) at 160^3, 3 sweeps: this default 684 iterations, rounds 1-2's sweep "
+                                          "943-981, the interleaved order 1173-1196, synchronous sweeps 655: "
+                                          "profiles/r03_sweep_order_quality.txt)")
                 if bs in (4, 8):
                     # the other row order inside a chunk, measured beside the default: interleaved (a row's predecessor
                     # belongs to the step before) -- closer to the exact solves per sweep, 10 % dearer per sweep, and no
@@ -610,7 +615,7 @@ def main():
                                "ms_per_step": alt_ms, "value": s / (alt_ms * 1e-3), "unit": "sweeps/s",
                                "lower_ms": ta["lower_ms"] / max(ta["lower_launches"], 1), "upper_ms": ums,
                                "upper_frac": ab["upper_sweep"] / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS if ums > 0 else 0.0,
-                               "gcr_iterations_160": {"natural, 3 / 5 sweeps": "943-960 / 516-517",
+                               "gcr_iterations_160": {"default (late store, 2 steps in flight), 3 / 5 sweeps": "684 / 498",
                                                       "interleaved, 3 / 5 sweeps": "1173-1196 / 510-511",
                                                       "source": "profiles/r03_sweep_order_quality.txt"}}
                         alt.update(quality_figures(p, capi, torch, r, z, s))
