@@ -22,7 +22,8 @@ def one(pattern):
 CONFIG_KERNELS = {
     "1": ("poisson3d_64_csr_async_ilu0_apply", ("sweep_kernel<1, false, 1,",)),
     # (bench.py also times the interleaved row order beside the default: the IW instantiation, last template argument true)
-    "2": ("ilu_apply", ("sweepw_kernel<4, 1, 1, 1, 128, true, 1, 1, false, false, false>", "sweepw_kernel<4, 1,", "sweep_kernel<")),
+    # (default in-place sweep: natural order, late store, two row steps in flight = UNR 2, LS true)
+    "2": ("ilu_apply", ("sweepw_kernel<4, 1, 1, 1, 128, true, 2, 1, false, false, false, true>", "sweepw_kernel<4, 1,", "sweep_kernel<")),
     "3": ("poisson3d_256_bs4_async_block_sgs_relaxation", ("sweepw_kernel<4, 2,",)),
     "4": ("unstructured_126_bs5_async_block_ilu0_apply", ("sweepodd_kernel<5, 1,", "sweepx_kernel<5, 1,")),
     "5": ("poisson3d_100_bs8_block_ilu0_apply", ("sweepw_kernel<8, 1,",)),
@@ -105,9 +106,9 @@ def main(tag, op="ilu_apply"):
     if dom:
         cur[op] = entry(dom[0])
     # side kernels of the default configuration's run: the factorisation sweep and the exact (level-scheduled) passes
-    extras = {"factor": ("factor4_kernel",), "ilu_apply_interleaved_order": ("sweepw_kernel<4, 1, 1, 1, 128, true, 1, 1, false, false, true>",),
+    extras = {"factor": ("factor4_kernel",), "ilu_apply_interleaved_order": ("sweepw_kernel<4, 1, 1, 1, 128, true, 1, 1, false, false, true, false>",),
               "exact_lower_pass": ("sfw_kernel<4, false",), "exact_upper_pass": ("sfw_kernel<4, true",),
-              "lower_sweep": ("sweepw_kernel<4, 0, 0, 0, 128, true, 1, 1, false, false, false>",)}
+              "lower_sweep": ("sweepw_kernel<4, 0, 0, 0, 128, true, 2, 1, false, false, false, true>",)}
     if op == "ilu_apply":
         for name, frags in extras.items():
             ks = sorted([k for k in pmc if any(f in k for f in frags) and "hbm_bytes_per_launch" in pmc[k]],
