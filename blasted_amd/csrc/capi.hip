@@ -1763,6 +1763,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
 			set_levelw_enabled(spec[10] - '0');
+		else if (spec && std::strncmp(spec, "invertrow=", 10) == 0)
+			set_invert_rowlane(spec[10] != '0');  // eight-lanes-per-block inversion of 5 <= bs <= 8 diagonal blocks
 		else if (spec && std::strncmp(spec, "latestore=", 10) == 0)
 			g_late_store = (spec[10] == '0' || spec[10] == '1' || spec[10] == '2' || spec[10] == '4') ? spec[10] - '0' : 2;  // row steps in flight; 0: stores step by step
 		else if (spec && std::strncmp(spec, "gatherprobe=", 12) == 0)

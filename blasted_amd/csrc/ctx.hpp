@@ -166,6 +166,7 @@ void launch_level_unpermute(const LevelSchedule &ls, int bs, const double *xperm
 void set_levelw_enabled(int on);
 void set_syncfree_one_step(int on);
 void set_level_fast(int on);
+void set_invert_rowlane(int on);
 void set_syncfree_nowait(int on);
 void set_level_serial_after(long n);
 void build_natural_storage(const Pattern &pat, LevelSchedule &ns, hipStream_t s);

@@ -376,6 +376,147 @@ __global__ __launch_bounds__(64) void invert_blocks_tpb_kernel(const Pattern pat
 	}
 }
 
+// Round 3: the same Gauss-Jordan for 5 <= bs <= 8 with EIGHT LANES per block -- lane r of an aligned 8-lane group holds
+// row r (bs doubles), eight blocks per wave.  Between round 2's two forms: the thread-per-block kernel above needs no
+// cross-lane traffic but 160-215 registers and an LDS transpose (four to twelve waves per CU; 0.45 ms per 10^6 8x8
+// blocks, 0.53 ms per 2*10^6 5x5 blocks: 1.5-2.3 TB/s), the 64-lanes-per-block form put one block's eight dependent
+// steps on a whole wave (1.0 ms).  Here a step is: pivot search = a three-step (value, index) butterfly inside the
+// group (DPP), the pivot row broadcast from its lane (two DPP moves per word), one FMA per held entry; rows are
+// exchanged by a permute only when a pivot is off the diagonal (a wave-uniform test).  42-64 registers (8 waves per
+// SIMD), loads and stores of bs contiguous doubles per group and column.  Measured (tools/invert_ab.py,
+// profiles/r03_invert_ab.txt): 10^6 8x8 blocks 0.454 -> 0.287 ms, 2*10^6 5x5 blocks 0.532 -> 0.271 ms, same inverses
+// to the last bit of the comparison with torch.linalg.inv (4e-16); three build sweeps of config 5 / config 4, whose
+// every sweep starts with this pass, 8.70 -> 8.07 ms / 16.78 -> 15.68 ms.  The operations on every entry are the thread-per-block
+// kernel's, in its order (same pivot choice: the first row of largest magnitude; NaN never wins a pivot search).
+template <int P>
+__device__ __forceinline__ double group8_bcast(const double v, const int lane)
+{
+	constexpr int Q = P & 3, CTRL = Q | (Q << 2) | (Q << 4) | (Q << 6);
+	const double t = dpp_mov<CTRL>(v);                                  // lane Q of the own quad
+	const double o = (P >> 2) ? dpp_mov<0x104>(t) : dpp_mov<0x114>(t);  // row_shl:4 / row_shr:4: the other quad's
+	return (((lane >> 2) & 1) == (P >> 2)) ? t : o;
+}
+
+// (p is a compile-time constant wherever this is called -- inside a fully unrolled loop -- so the switch folds)
+__device__ __forceinline__ double group8_bcast_p(const double v, const int p, const int lane)
+{
+	switch (p) {
+	case 0: return group8_bcast<0>(v, lane);
+	case 1: return group8_bcast<1>(v, lane);
+	case 2: return group8_bcast<2>(v, lane);
+	case 3: return group8_bcast<3>(v, lane);
+	case 4: return group8_bcast<4>(v, lane);
+	case 5: return group8_bcast<5>(v, lane);
+	case 6: return group8_bcast<6>(v, lane);
+	default: return group8_bcast<7>(v, lane);
+	}
+}
+
+__device__ __forceinline__ int dpp_xor_int(const int v, const int which, const int lane)
+{
+	if (which == 1)
+		return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+	if (which == 2)
+		return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+	const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, false);
+	const int dn = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+	return (lane & 4) ? dn : up;
+}
+
+__device__ __forceinline__ double dpp_xor_double(const double v, const int which, const int lane)
+{
+	if (which == 1)
+		return dpp_mov<0xB1>(v);
+	if (which == 2)
+		return dpp_mov<0x4E>(v);
+	return xor4_value(v, lane);
+}
+
+template <int BS, bool RM>
+__global__ __launch_bounds__(256) void invert_blocks_rowlane_kernel(const Pattern pat, const double *src,
+                                                                    const int src_by_diag, double *dst,
+                                                                    const int dst_by_diag)
+{
+	static_assert(BS >= 5 && BS <= 8, "eight lanes per block: 5 <= bs <= 8");
+	constexpr int BS2 = BS * BS;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane >> 3, r = lane & 7;
+	const long lin = ((long)blockIdx.x * 4 + wave) * 8 + g;
+	const bool ok = lin < pat.nbrows;
+	const int i = ok ? (int)lin : 0;
+	const long dgpos = ok ? pat.diagind[i] : 0;
+	const long sblk = src_by_diag ? dgpos : i, dblk = dst_by_diag ? dgpos : i;
+	const bool act = ok && r < BS;
+
+	double m[BS];
+#pragma unroll
+	for (int c = 0; c < BS; c++)
+		m[c] = act ? src[sblk * BS2 + (RM ? r * BS + c : c * BS + r)] : ((r == c) ? 1.0 : 0.0);
+
+	int piv[BS];
+#pragma unroll
+	for (int p = 0; p < BS; p++) {
+		// the first row r >= p of largest |m[r][p]| (a NaN is taken only where the thread-per-block kernel takes it: at p)
+		double v = (r >= p && r < BS) ? fabs(m[p]) : -1.0;
+		if (v != v)
+			v = (r == p) ? __builtin_huge_val() : -1.0;
+		int idx = r;
+#pragma unroll
+		for (int w = 1; w <= 4; w <<= 1) {
+			const double ov = dpp_xor_double(v, w, lane);
+			const int oi = dpp_xor_int(idx, w, lane);
+			const bool take = (ov > v) || (ov == v && oi < idx);
+			v = take ? ov : v;
+			idx = take ? oi : idx;
+		}
+		const int pr = idx;
+		piv[p] = pr;
+		if (__builtin_amdgcn_ballot_w64(pr != p) != 0ull) {
+			const int partner = (r == p) ? pr : ((r == pr) ? p : r);
+			const int srcl = (lane & ~7) | partner;
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[c] = __shfl(m[c], srcl, 64);
+		}
+		if (r == p) {
+			const double pinv = 1.0 / m[p];
+			m[p] = 1.0;
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[c] *= pinv;
+		}
+		double prow[BS];
+#pragma unroll
+		for (int c = 0; c < BS; c++)
+			prow[c] = group8_bcast_p(m[c], p, lane);
+		if (r != p) {
+			const double f = m[p];
+			m[p] = 0.0;
+#pragma unroll
+			for (int c = 0; c < BS; c++)
+				m[c] -= f * prow[c];
+		}
+	}
+	// undo the row swaps as column swaps, last first
+#pragma unroll
+	for (int p = BS - 1; p >= 0; p--) {
+#pragma unroll
+		for (int q = p + 1; q < BS; q++) {
+			const bool sw = (piv[p] == q);
+			const double a = m[p], b = m[q];
+			m[p] = sw ? b : a;
+			m[q] = sw ? a : b;
+		}
+	}
+	if (act) {
+#pragma unroll
+		for (int c = 0; c < BS; c++)
+			dst[dblk * BS2 + (RM ? r * BS + c : c * BS + r)] = m[c];
+	}
+}
+
+int g_invert_rowlane = 1;  // tuning "invertrow=0|1": the eight-lanes-per-block inversion for 5 <= bs <= 8
+
 // INIT_F_ORIGINAL with scaling / INIT_F_SGS first pass: ilu = scaled A
 template <int BS, bool RM>
 __global__ void scaled_copy_kernel(const Pattern pat, const double *avals, const double *scale,
@@ -887,6 +1028,11 @@ __global__ __launch_bounds__(256, (ME == 4 && BS == 5) ? 8 : 1) void sffplan_ker
 static int g_factor_syncfree = 1;
 static int g_factor_plan = 1;  // "factorsf=p0|p1": plan kernel for block sizes other than 1 and 4 off | on
 static int g_factor_fake_abort = 0;  // "factorsf=a1": tests -- behave as if a wave had given up waiting
+void set_invert_rowlane(int on)
+{
+	g_invert_rowlane = on != 0;
+}
+
 void set_factor_syncfree(int on)
 {
 	if (on >= 20)
@@ -1063,7 +1209,11 @@ void launch_invert_diag_blocks(const Pattern &pat, const double *src, long src_b
 	if (pat.nbrows == 0)
 		return;
 	BHIP_BS_SWITCH(pat.bs, pat.rowmajor, {
-		if (BS >= 5) {
+		if (BS >= 5 && g_invert_rowlane) {
+			const unsigned grid = (unsigned)(((long)pat.nbrows + 31) / 32);
+			hipLaunchKernelGGL((invert_blocks_rowlane_kernel<(BS >= 5 ? BS : 5), RM>), dim3(grid), dim3(256), 0, s,
+			                   pat, src, (int)src_by_diag, dst, (int)dst_by_diag);
+		} else if (BS >= 5) {
 			const unsigned grid = (unsigned)(((long)pat.nbrows + 63) / 64);
 			hipLaunchKernelGGL((invert_blocks_tpb_kernel<(BS >= 5 ? BS : 5), RM>), dim3(grid), dim3(64), 0, s,
 			                   pat, src, (int)src_by_diag, dst, (int)dst_by_diag, (const int *)nullptr, 0);
