@@ -576,6 +576,8 @@ def main():
                                  "touched_bytes_per_sweep": tb, "fixed_upper_blocks": ab["fixed_upper"],
                                  "achieved": tb / (fms * 1e-3) / 1e9 if fms > 0 else 0.0,
                                  "frac": tb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else 0.0,
+                                 "moved_gbps": (ftraffic["hbm_bytes_per_launch"] / (fms * 1e-3) / 1e9
+                                                if ftraffic and ftraffic.get("hbm_bytes_per_launch") and fms > 0 else None),
                                  "note": "in-place sweeps leave upper blocks without position pairs alone (their value "
                                          "is the matrix block): achieved / frac count the bytes the sweep touches, not "
                                          "the every-array-once figure"}

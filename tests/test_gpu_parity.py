@@ -780,6 +780,38 @@ def test_async_sweeps_are_never_worse_than_synchronous_ones_64(interleave):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["poisson16_bs4", "2dcyl1_bs4_col", "random_bs4"])
+def test_in_place_sweep_variants_reach_the_exact_solves(golden, case):
+    """Every form of the in-place bs = 4 triangular sweep -- results stored step by step (rounds 1-2) or once per
+    workgroup with 1, 2 (default) or 4 row steps of a wave in flight; natural row order, interleaved with the wave's
+    registers, interleaved through memory -- is the same fixed-point iteration: run past the dependency depth it gives
+    the exact triangular solves (<= 1e-10), and synchronous sweeps are bit-identical whatever the setting."""
+    m = matrices(golden)[case]()
+    r = W.rhs_vector(m["nbrows"] * m["bs"])
+    p = make_prec(m)
+    p.ilu0_factorize(-1)
+    f = p.get_iluvals()
+    ze = O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL)
+    nsw = int(W.dependency_levels(m).max()) + 3
+    p.jacobi_compute()
+    zsgs = O.sgs_apply(m, O.jacobi_compute(m), r, 1, mode=O.GS_SERIAL)
+    sync_ref = None
+    try:
+        for spec in ("latestore=0", "latestore=1", "latestore=2", "latestore=4", "interleave=1", "interleave=2"):
+            capi.set_tuning(spec)
+            assert rel(p.ilu0_apply(r, nsw, mode=capi.ASYNC), ze) < TOL_EXACT, spec
+            assert rel(p.sgs_apply(r, nsw, mode=capi.ASYNC), zsgs) < TOL_EXACT, spec
+            zs = p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC)
+            sync_ref = zs if sync_ref is None else sync_ref
+            assert np.array_equal(zs, sync_ref), spec
+            if spec.startswith("interleave"):
+                capi.set_tuning("interleave=0")
+    finally:
+        capi.set_tuning("interleave=0")
+        capi.set_tuning("latestore=2")
+    p.close()
+
+
 def test_interleaved_sweep_forwards_the_finished_row_in_registers():
     """The interleaved row order with the wave's registers (kernels_sweepw.hip, IW), pinned deterministically: on 32
     block-rows ONE wave owns the whole sweep -- lane group g takes rows 4g .. 4g+3 in its four steps -- so an in-place
