@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	//     synchronous sweeps (mode DETERMINISTIC)                0            655     / -         (2 of 3 sweeps read the matrix)
 	// i.e. among in-place sweeps on this GPU the more repeatable operator is the better one, down to the synchronous
 	// sweeps' iteration count, and two steps in flight with a late store is also the fastest form.
-	static_assert(!LS || (BS == 4 && (UNR == 1 || UNR == 2 || UNR == 4) && NBV == 1 && !SC && !IW && (PART == PART_LOWER || PART == PART_UPPER)), "late store");
+	// bs = 8 (two 16-byte pieces per lane, one row step in flight), 100^3: 0.691 against 0.719 ms per sweep pair, two
+	// applications differ by 5.7e-3 instead of 1.9e-2, GCR(30) 313 iterations instead of 363-365 at 3 sweeps.
+	static_assert(!LS || (((BS == 4 && (UNR == 1 || UNR == 2 || UNR == 4)) || (BS == 8 && UNR == 1)) && NBV == 1 && !SC && !IW &&
+	                      (PART == PART_LOWER || PART == PART_UPPER)), "late store");
 	static_assert(!IW || (BS == 4 && UNR == 1 && NBV == 1 && !SC && (PART == PART_LOWER || PART == PART_UPPER)),
 	              "register-carried interleave: bs 4, triangular sweeps, one slot per row, one step in flight");
 
@@ -202,8 +205,14 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	static_assert(!IW || NSTEPS_W * HB == G, "a lane group's pieces of the window must be its own lanes");
 	double2_t win_r;
 	win_r.x = win_r.y = 0.0;
-	double2_t late_o;
-	late_o.x = late_o.y = 0.0;
+	// LS: a lane keeps one 16-byte piece per slot -- piece (q % HB) of the row its group computes in step
+	// slot * (G / HB) + q / HB (bs = 4: 4 steps, one slot; bs = 8: 16 steps, two slots)
+	constexpr int LS_SPAN = G / HB;                                      // steps covered by one slot
+	constexpr int LS_SLOTS = LS ? (RCHUNK / RSTEP + LS_SPAN - 1) / LS_SPAN : 1;
+	double2_t late_o[LS_SLOTS];
+#pragma unroll
+	for (int j = 0; j < LS_SLOTS; j++)
+		late_o[j].x = late_o[j].y = 0.0;
 	const bool inplace = a.xin == a.xout;
 	double prev0 = 0.0, prev1 = 0.0;  // the group's result of the step before (rows 2h, 2h+1)
 	if (IW) {
@@ -475,9 +484,13 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				prev1 = o1;
 			}
 			if (LS) {
-				if ((q >> 1) == step0 + u) {  // lane (g, q) keeps the result of step q / 2, half q % 2 = h
-					late_o.x = o0;
-					late_o.y = o1;
+				const int st = step0 + u;
+#pragma unroll
+				for (int j = 0; j < LS_SLOTS; j++) {
+					if (st / LS_SPAN == j && (q / HB) == st % LS_SPAN) {  // (o0, o1) of a lane are piece h = q % HB of its row
+						late_o[j].x = o0;
+						late_o[j].y = o1;
+					}
 				}
 			} else if (ok[u] && slot == 0 && q < HB) {
 				double2_t o2;
@@ -499,10 +512,13 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 		}
 	}
 	if (LS) {
-		const int ls = (q >> 1) * RSTEP + wave * RPW + g;
-		if (ls < rc) {
-			const int lr = descending ? rc - 1 - ls : ls;
-			*reinterpret_cast<double2_t *>(obase + ((unsigned)lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q & 1))) = late_o;
+#pragma unroll
+		for (int j = 0; j < LS_SLOTS; j++) {
+			const int ls = (j * LS_SPAN + q / HB) * RSTEP + wave * RPW + g;
+			if (slot == 0 && ls < rc) {
+				const int lr = descending ? rc - 1 - ls : ls;
+				*reinterpret_cast<double2_t *>(obase + ((unsigned)lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q % HB))) = late_o[j];
+			}
 		}
 	}
 }
@@ -580,6 +596,7 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 			/* interleaved row order through the wave's registers (IW, see the kernel); "interleave=2" keeps the  \
 			   round-1 form that goes through memory */                                                     \
 			constexpr bool IWOK = BS == 4 && RV == 128 && UV == 1 && (PART == PART_LOWER || PART == PART_UPPER); \
+			constexpr bool LS8OK = BS == 8 && RV == 128 && UV == 1 && (PART == PART_LOWER || PART == PART_UPPER); \
 			if (longest_part > KSTRAIGHT + 1 && UN1 == 1)                                                  \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, true>), \
 				                   dim3(grid), dim3(256), 0, s, a);                                        \
@@ -591,6 +608,9 @@ static bool launch_variant(const SweepArgs &a, const Variant &v, hipStream_t s)
 				                   dim3(grid), dim3(256), 0, s, a);                                        \
 			else if (IWOK && a.latestore && !a.interleave && a.xin == a.xout)                              \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, false, IWOK>), \
+				                   dim3(grid), dim3(256), 0, s, a);                                        \
+			else if (LS8OK && a.latestore && !a.interleave && a.xin == a.xout)                             \
+				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, false, LS8OK>), \
 				                   dim3(grid), dim3(256), 0, s, a);                                        \
 			else if (IWOK && a.interleave == 1)                                                            \
 				hipLaunchKernelGGL((sweepw_kernel<BS, PART, POST, DSRC, RV, (NTV != 0), 1, 1, false, false, IWOK>), \
