@@ -390,6 +390,8 @@ static void restore_ytemp(blasted_hip_prec p)
 // The exact ILU solves with a level-ordered iterate (kernels_levelw.hip, PERM): the lower solve leaves y in
 // p->yperm, the upper solve reads it there, gathers from p->zperm and also writes z in natural order to x.
 // Returns 0 when this form does not apply (the caller continues with the natural-order forms).
+constexpr long SF_ABORT_LIMIT = 3;  // see exact_pass
+
 static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, double *x, LevelSchedule &ls,
                                const LevelView &view, bool sgs)
 {
@@ -431,7 +433,10 @@ static int exact_pass(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSr
 	if (p->pat.nbrows == 0)
 		return 0;  // an empty subdomain: nothing to solve
 	LevelSchedule &ls = need_levels(p);
-	if (g_level_impl == 0) {
+	// A dependency-polling launch that has to give up costs its whole spin budget (seconds) before the per-level
+	// launches redo the pass: an operator whose single-launch passes have given up SF_ABORT_LIMIT times (another
+	// tenant holding compute units, a device where the dispatch order assumed here does not hold) stops trying.
+	if (g_level_impl == 0 && ls.sf_aborts < SF_ABORT_LIMIT) {
 		LevelView view;
 		const bool triangular = part == PART_LOWER || part == PART_UPPER;
 		bool use_view = false;
@@ -919,7 +924,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 			LevelSchedule &ls = need_levels(p);
 			// one launch whose rows wait for their predecessors, so that levels overlap ("level=launch" keeps one
 			// launch per level, as for the exact solves)
-			const int sf = g_level_impl == 0 ? launch_factor_syncfree(fa, ls, p->stream) : 0;
+			const int sf = (g_level_impl == 0 && ls.sf_aborts < SF_ABORT_LIMIT) ? launch_factor_syncfree(fa, ls, p->stream) : 0;
 			if (sf != 0)
 				ls.sf_launches++;
 			if (sf == 1)

@@ -265,6 +265,23 @@ def test_exact_factorisation_falls_back_when_a_wave_gives_up(golden, case):
     assert np.all(np.isfinite(f1)) and np.array_equal(f0, f1)
     if st["syncfree_passes"] != before["syncfree_passes"]:   # ("level=launch" never tries the single launch)
         assert st["syncfree_aborts"] == before["syncfree_aborts"] + 1
+        # an operator whose single-launch passes keep giving up stops trying (a give-up costs the whole spin budget):
+        # after the third one the per-level launches are used straight away, for the solves too
+        capi.set_tuning("factorsf=a1")
+        try:
+            for _ in range(4):
+                p.ilu0_factorize(-1)
+            st2 = p.level_stats()
+            assert np.array_equal(f0, p.get_iluvals())
+        finally:
+            capi.set_tuning("factorsf=a0")
+        assert st2["syncfree_aborts"] == before["syncfree_aborts"] + 3
+        p.ilu0_factorize(-1)
+        r = W.rhs_vector(m["nbrows"] * m["bs"])
+        z = p.ilu0_apply(r, 1, mode=capi.LEVEL)
+        st3 = p.level_stats()
+        assert st3["syncfree_passes"] == st2["syncfree_passes"] and st3["syncfree_aborts"] == st2["syncfree_aborts"]
+        assert rel(z, O.ilu0_apply(m, O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"], r, 1, mode=O.GS_SERIAL)) < TOL
     p.close()
 
 
