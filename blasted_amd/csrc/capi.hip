@@ -507,7 +507,7 @@ static int g_interleave = [] {
 }();
 
 // tuning ("xcdsuper=N", N a power of two): the XCDs take turns on super-chunks of N consecutive chunks (lanes.hpp)
-static int g_xcd_shift = 4;
+static int g_xcd_shift = -1;  // -1: each kernel family's own default (16 chunks per turn; 64 for the odd block sizes)
 
 // tuning ("relaxsplit=0|1"): exact relaxation passes as product + exact triangular solve (default) or as one
 // whole-row exact kernel
@@ -1799,9 +1799,13 @@ int blasted_hip_set_tuning(const char *spec)
 			int sh = 0;
 			while ((1 << sh) < n && sh < 12)
 				sh++;
-			if (n < 1 || (1 << sh) != n)
-				BHIP_FAIL(BLASTED_HIP_EINVAL, "xcdsuper: a power of two between 1 and 4096");
-			g_xcd_shift = sh;
+			if (std::strcmp(spec + 9, "auto") == 0)
+				g_xcd_shift = -1;
+			else {
+				if (n < 1 || (1 << sh) != n)
+					BHIP_FAIL(BLASTED_HIP_EINVAL, "xcdsuper: a power of two between 1 and 4096, or auto");
+				g_xcd_shift = sh;
+			}
 		} else if (spec && std::strncmp(spec, "copies=", 7) == 0)
 			g_keep_both_copies = std::strcmp(spec + 7, "both") == 0;
 		else if (spec && std::strncmp(spec, "sgsfwd=", 7) == 0)

@@ -68,7 +68,8 @@ struct SweepArgs {
 	double *xnat;           // level-ordered exact solves: optional second output in natural row order
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
-	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp), default 4
+	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp); -1 = the
+	                        // launcher's default: 4 (16 chunks per turn), 6 for the odd block sizes (kernels_sweepodd.hip)
 	int interleave;         // in-place sweeps: rows of one step are taken a step count apart (see kernels_sweepw.hip)
 	int latestore;          // in-place bs=4 triangular sweeps in natural order store a chunk's results once (kernels_sweepw.hip, LS)
 	int probe;              // measurements only (tuning "gatherprobe=1", WRONG results): kernels_sweepodd.hip gathers

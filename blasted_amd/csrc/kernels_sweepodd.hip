@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 	const bool hiA = cA != cx, hiB = cB != cx;
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)a.xcd_shift);
+	// (default here: the XCDs take turns on 64 chunks = 8192 rows, not 16 -- on the unstructured configuration an XCD
+	// then owns whole windows of the numbering and its L2 serves more of the gathers: lower / upper sweep 0.706 / 0.826 ->
+	// 0.674 / 0.804 ms, no change on stencil matrices, none in GCR iterations: profiles/r03_xcdsuper.txt)
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)(a.xcd_shift < 0 ? 6 : a.xcd_shift));
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	const int c = q / HB, h = q % HB;  // column of this lane's two entries, row pair (2h, 2h+1)
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)a.xcd_shift);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)(a.xcd_shift < 0 ? 4 : a.xcd_shift));
 	// rows of this chunk in index order: [r0, r0 + rc)
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);

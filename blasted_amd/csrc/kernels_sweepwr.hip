@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void sweepwr_kernel(const SweepArgs a)
 	const int gbase = lane & ~(G - 1);
 
 	const int nb = a.pat.nbrows;
-	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)a.xcd_shift);
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)(a.xcd_shift < 0 ? 4 : a.xcd_shift));
 	const long lin0 = (long)chunk * RCHUNK;
 	const int rc = (int)((nb - lin0) < RCHUNK ? (nb - lin0) : RCHUNK);
 	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;

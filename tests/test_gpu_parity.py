@@ -232,7 +232,7 @@ def test_xcd_super_chunk_size_does_not_change_results(bs):
         with pytest.raises(capi.BlastedHipError):
             capi.set_tuning("xcdsuper=12")
     finally:
-        capi.set_tuning("xcdsuper=16")
+        capi.set_tuning("xcdsuper=auto")
     p.close()
 
 

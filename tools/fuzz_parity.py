@@ -144,7 +144,7 @@ def main():
         p.close()
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
-                 "factor8=1", "gunroll=0", "copies=one", "xcdsuper=16", "levelserial=4096", "levelfast=1",
+                 "factor8=1", "gunroll=0", "copies=one", "xcdsuper=auto", "levelserial=4096", "levelfast=1",
                  "factorsf=1", "factorsf=p1", "factorskip=1", "latestore=2", "invertrow=1", "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
