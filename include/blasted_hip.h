@@ -54,7 +54,8 @@ enum { BLASTED_HIP_HOST = 0, BLASTED_HIP_DEVICE = 1 };
  * callers that need a FIXED linear operator (any non-flexible Krylov method): synchronous sweeps like
  * JACOBI_SYNC -- the same sweep counts, run-to-run identical results -- except that the forward half of
  * sgs_apply is the exact in-order solve, as it is in the reference at every thread count
- * (src/solverops_sgs.cpp:62-66).  What the host C++ layer passes by default. */
+ * (src/solverops_sgs.cpp:62-66).  The host C++ layer passes ASYNC by default (the reference's semantics; round 2
+ * passed DETERMINISTIC) and DETERMINISTIC / LEVEL on request (-blasted_sweep_mode, BLASTED_HIP_SWEEP_MODE). */
 enum { BLASTED_HIP_ASYNC = 0, BLASTED_HIP_JACOBI_SYNC = 1, BLASTED_HIP_LEVEL = 2, BLASTED_HIP_DETERMINISTIC = 3 };
 
 /* include/async_initialization_decl.hpp:15-34, same numeric values as FactInit / ApplyInit */
@@ -213,8 +214,9 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * per dependency level (environment: BLASTED_HIP_LEVEL).  "levelstore=1" (default) / "levelstore=0":
  * exact triangular solves read level-ordered copies of the factor's triangles (one extra copy of the
  * factor, permuted once per factorisation) or the factor in place (environment: BLASTED_HIP_LEVELSTORE);
- * "interleave=1": interleaved row order inside a chunk for the in-place sweeps (1.46x fewer sweeps for the
- * same accuracy, 13-15 % slower per sweep; default 0; environment: BLASTED_HIP_INTERLEAVE).
+ * "interleave=1": interleaved row order inside a chunk for the in-place triangular sweeps (closer to the exact
+ * solves per sweep, 10 % slower per sweep, no better inside a flexible Krylov solver; default 0; environment:
+ * BLASTED_HIP_INTERLEAVE).
  * "relaxsplit=1" (default) / "relaxsplit=0": an exact relaxation pass runs as a product with the other
  * triangle from the previous iterate plus an exact triangular solve, or as one whole-row exact kernel.
  * "compact=1" (default) / "compact=0": asynchronous ILU sweeps read natural-order compact copies of the
@@ -235,8 +237,16 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * "factorsf=a1" / "levelfast=2" make the single-launch factorisation / the polling launch of the schedule build
  * behave as if a wave had given up waiting, so that the fall-backs run.  "factorskip=1" (default) / "factorskip=0": in-place factorisation sweeps leave
  * upper blocks without position pairs alone once they hold their value (the scaled matrix block), or visit
- * every entry in every sweep.  "xcdsuper=N", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
- * measurement switches described where they are read (capi.hip). */
+ * every entry in every sweep.  "xcdsuper=N|auto", "levelserial=N", "sweepodd=nt0|nt1|occ0|occ1":
+ * measurement switches described where they are read (capi.hip).
+ * Round 3: "interleave=0" (default) / "1" (interleaved row order of the in-place bs=4/8 triangular sweeps, the
+ * finished row handed on in registers at bs=4) / "2" (the round-1 form through memory) / "3" (that form for
+ * relaxation passes too); "latestore=2" (default) / "0|1|4": the in-place bs=4 triangular sweeps store a workgroup's
+ * rows once, with 2 (1, 4) row steps of a wave in flight, or step by step (0) -- bs=8: any non-zero value = stored
+ * once (environment: BLASTED_HIP_LATESTORE); "invertrow=1" (default) / "0": diagonal blocks of size 5..8 inverted
+ * by eight lanes per block or by one thread per block.  Measurement hooks that give WRONG results (timing
+ * experiments only): "levelnowait=1" (exact passes with nobody waiting), "gatherprobe=1" (odd block sizes gather
+ * their own row), "gatherprobe=2|3" (store probes of the interleaved sweeps). */
 int blasted_hip_set_tuning(const char *spec);
 
 /* ---- per-phase HIP-event timing (bench.py roofline) -------------------------------------- */
