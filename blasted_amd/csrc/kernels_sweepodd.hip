@@ -45,6 +45,11 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 // OCC: waves per SIMD the register allocation must leave room for (second launch bound).  Left alone the
 // compiler spends 78-86 VGPRs on the triangular sweeps (5 waves per SIMD); asked for 6 it needs 62-70 without a
 // spill, i.e. 7-8 resident waves -- and resident waves are bytes in flight, which is what bounds this kernel.
+// (Round 3, built, verified -- 955 parity / level / fuzz tests green -- measured and removed: the late store of
+// kernels_sweepw.hip for this kernel, G / bs steps sharing one result register through a lane permute and the
+// workgroup's rows stored once after the last step.  8-10 more registers = one wave per SIMD less: the unstructured
+// sweeps 0.9 % and Poisson 128^3 bs=5 1.6 % SLOWER; two applications differ by 6.4e-3 instead of 1.9e-2 and GCR(30)
+// needs 310 instead of 337 iterations at 3 sweeps, 193 against 191 at 5 (100^3 bs=5): too little either way.)
 template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 {
