@@ -26,7 +26,7 @@ CONFIG_KERNELS = {
     "2": ("ilu_apply", ("sweepw_kernel<4, 1, 1, 1, 128, true, 2, 1, false, false, false, true>", "sweepw_kernel<4, 1,", "sweep_kernel<")),
     "3": ("poisson3d_256_bs4_async_block_sgs_relaxation", ("sweepw_kernel<4, 2,",)),
     "4": ("unstructured_126_bs5_async_block_ilu0_apply", ("sweepodd_kernel<5, 1,", "sweepx_kernel<5, 1,")),
-    "5": ("poisson3d_100_bs8_block_ilu0_apply", ("sweepw_kernel<8, 1,",)),
+    "5": ("poisson3d_100_bs8_block_ilu0_apply", ("sweepw_kernel<8, 1, 1, 1, 128, true, 1, 1, false, false, false, true>", "sweepw_kernel<8, 1,")),
 }
 
 
