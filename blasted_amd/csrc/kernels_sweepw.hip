@@ -570,7 +570,9 @@ static bool launch_variant(const SweepArgs &a, const Variant &v_, hipStream_t s)
 	// Synchronous (double-buffered) bs = 4 triangular sweeps take two row steps in flight: a row of such a sweep depends
 	// on nothing the launch writes, so the result is the same bits and the sweep 1.5-2 % faster (round 2's u2 A/B)
 	Variant v = v_;
-	if (BS == 4 && (PART == PART_LOWER || PART == PART_UPPER) && a.xin != a.xout && v.rchunk == 128 && v.unr == 1)
+	// (stencil-like rows only: longer row parts keep the one-step instantiation with the grouped remainder passes)
+	if (BS == 4 && (PART == PART_LOWER || PART == PART_UPPER) && a.xin != a.xout && v.rchunk == 128 && v.unr == 1 &&
+	    (a.pat.max_row_len + 1) / 2 + 1 <= 5)
 		v.unr = 2;
 #define BHIP_V(RV, NTV, UV)                                                                            \
 	if (v.rchunk == RV && v.nt == NTV && v.unr == UV) {                                                \
