@@ -516,6 +516,9 @@ static int g_relax_split = 1;
 // tuning ("factorskip=0|1"): in-place factorisation sweeps after the first leave upper blocks without position
 // pairs alone (their value, the scaled matrix block, does not change from sweep to sweep)
 static int g_factor_skip_fixed = 1;
+// tuning ("factor1plan=0|1"): scalar in-place factorisation sweeps on the precomputed plan (kernels_factor1.hip,
+// factor1p_kernel; default) or with the round-2 kernel
+static int g_factor1_plan = 1;
 
 // tuning ("sgsfwd=exact|async"): the forward half of an ASYNC-mode SGS application as one exact in-order pass (the
 // reference's semantics, default) or as napplysweeps asynchronous sweeps
@@ -647,6 +650,8 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		dev_free(p->posptr);
 		dev_free(p->lowerp);
 		dev_free(p->upperp);
+		dev_free(p->f1_dcol);
+		dev_free(p->f1_chunks);
 		dev_free(p->iluvals);
 		dev_free(p->iluvals2);
 		dev_free(p->finv);
@@ -896,6 +901,16 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.diag_inverted = 0;
 		fa.skip_fixed = 0;
 		fa.dinv_scratch = nullptr;
+		if (pat.bs == 1 && nbuildsweeps > 0 && mode != BLASTED_HIP_JACOBI_SYNC && !scale && g_factor1_plan) {
+			// once per pattern: what the scalar in-place sweep kernel reads instead of column indices
+			if (!p->f1_dcol) {
+				p->f1_dcol = dev_alloc<int>((size_t)pat.nnzb);
+				p->f1_chunks = dev_alloc<int4>((size_t)factor1_plan_chunks(pat.nbrows));
+				build_factor1_plan(pat, p->posptr, p->f1_dcol, p->f1_chunks, p->stream);
+			}
+			fa.f1_dcol = p->f1_dcol;
+			fa.f1_chunks = p->f1_chunks;
+		}
 		if (pat.bs >= 5)
 			fa.dinv_scratch = ensure(p->finv, (long)pat.nbrows * pat.bs * pat.bs);
 
@@ -1788,6 +1803,10 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
 			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
+		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)
+			g_factor1_plan = spec[12] != '0';
+		else if (spec && std::strncmp(spec, "scalarlane=", 11) == 0)
+			set_scalar_lane(spec[11] - '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
 			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
 		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)

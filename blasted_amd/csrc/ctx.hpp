@@ -135,6 +135,8 @@ struct FactorArgs {
 	                        // final, and lower blocks multiply with the stored inverse (general kernel only)
 	int skip_fixed;         // in-place sweeps after the first: an upper block without position pairs is the (scaled)
 	                        // matrix block, which the sweep before has stored -- neither read nor written again
+	const int *f1_dcol = nullptr;    // scalar in-place sweeps (kernels_factor1.hip, factor1p_kernel): per entry, the
+	const int4 *f1_chunks = nullptr; // position of its column's diagonal entry (-1: not lower); per chunk, its ranges
 };
 
 // kernels_sweep.hip
@@ -148,6 +150,9 @@ void set_sweepw_variant(const char *spec);
 // kernels_sweepwr.hip (tuned bs=4/8 ROW-major path; false = not covered)
 bool launch_sweepwr(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepwr_enabled(int on);
+// kernels_sweep1.hip (scalar CSR with short rows, one lane per row; false = not covered)
+bool launch_sweep1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
+void set_scalar_lane(int v);
 // kernels_sweepodd.hip (tuned bs=3/5/7 column-major path; false = not covered)
 bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepodd_enabled(int on);
@@ -176,6 +181,8 @@ void launch_level_permute_values(const Pattern &pat, const LevelSchedule &ls, co
                                  double *lvals, double *uvals, hipStream_t s);
 // kernels_factor1.hip (scalar CSR factorisation sweep with chunk-staged operands)
 bool launch_factor1(const FactorArgs &a, hipStream_t s);
+long factor1_plan_chunks(int nbrows);
+void build_factor1_plan(const Pattern &pat, const int *posptr, int *dcol, int4 *chunks, hipStream_t s);
 void set_factor1_enabled(int on);
 // kernels_factor4.hip (tuned bs=4 column-major factorisation sweep on the matrix core)
 bool launch_factor4(const FactorArgs &a, hipStream_t s);
@@ -253,6 +260,8 @@ struct blasted_hip_prec_s {
 
 	int *posptr = nullptr, *lowerp = nullptr, *upperp = nullptr;
 	long npairs = -1;
+	int *f1_dcol = nullptr;     // scalar in-place factorisation sweeps: the plan of factor1p_kernel
+	int4 *f1_chunks = nullptr;
 
 	double *iluvals = nullptr, *iluvals2 = nullptr;
 	double *finv = nullptr;  // inverted diagonal blocks of the current iterate (bs >= 5 factorisation sweeps)

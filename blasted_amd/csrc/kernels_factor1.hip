@@ -193,6 +193,169 @@ __global__ __launch_bounds__(256) void factor1_kernel(const FactorArgs a)
 	}
 }
 
+// ---- round 3: the in-place sweep without scaling, on a precomputed plan ---------------------------------------------
+// What bounded factor1_kernel (0.29 of the HBM peak) is the dependent chain of a workgroup at four workgroups per
+// CU: two scalar range look-ups, the bulk loads, a barrier, a two-level gather (diagind[col], then u_jj), a second
+// barrier, a serial phase in which a lane divides three times.  Here
+//  * a per-pattern plan (f1_plan_kernel, once per pattern: 4 bytes per entry + 16 per chunk) holds, for every
+//    entry, the position of its column's diagonal entry (-1 for diagonal / upper entries) and, for every chunk, its
+//    entry and pair ranges -- so the ranges cost ONE scalar load, the column indices are not read at all, and
+//    u_jj is a one-level gather;
+//  * the thread that loaded an index issues the gather itself (no LDS round trip, no barrier in between);
+//  * a lower entry WITHOUT position pairs is l_ij = a_ij / u_jj outright: the loading thread divides, 256 lanes in
+//    parallel (the same operation on the same operands as in the serial phase: same bits);
+//  * LDS holds 16-bit chunk-relative positions: 28.5 KB per workgroup, five workgroups per CU;
+//  * the serial phase only visits entries that have pairs (a 7-point row: its diagonal entry).
+// Synchronous sweeps (separate buffers) and scaled factorisations keep factor1_kernel.
+constexpr int F1P_CAPE = 1024, F1P_CAPP = 1024;
+static_assert(F1P_CAPE == F1_CAPE && F1P_CAPP == F1_CAPP, "the chunk descriptors are built for these capacities");
+
+__global__ __launch_bounds__(256) void f1_plan_kernel(const Pattern pat, const int *__restrict__ posptr,
+                                                      int *__restrict__ dcol, int4 *__restrict__ chunks)
+{
+	const int row = blockIdx.x * 256 + threadIdx.x;
+	if (row >= pat.nbrows)
+		return;
+	const int jb = pat.browptr[row], je = pat.browptr[row + 1];
+	for (int j = jb; j < je; j++) {
+		const int col = pat.bcolind[j];
+		dcol[j] = col < row ? pat.diagind[col] : -1;
+	}
+	if (row % F1_RCHUNK == 0) {
+		const int rc = (pat.nbrows - row) < F1_RCHUNK ? (pat.nbrows - row) : F1_RCHUNK;
+		const int jhi = pat.browptr[row + rc];
+		const int nent = (jhi - jb) < F1P_CAPE ? (jhi - jb) : F1P_CAPE;
+		chunks[row / F1_RCHUNK] = make_int4(jb, jhi, posptr[jb], posptr[jb + nent]);
+	}
+}
+
+__global__ __launch_bounds__(256) void factor1p_kernel(const FactorArgs a)
+{
+	__shared__ unsigned short s_pp[F1P_CAPE + 2];  // first pair of an entry, relative to the chunk's first pair
+	__shared__ unsigned short s_lp[F1P_CAPP];      // a pair's lower entry, relative to the chunk's first entry
+	__shared__ double s_f[F1P_CAPE];               // matrix value, then the new factor value
+	__shared__ double s_dv[F1P_CAPE];              // lower entries: u_jj of their column
+	__shared__ double s_uv[F1P_CAPP];              // pairs: the upper factor u_kj
+	constexpr unsigned short FAR = 0xFFFF;
+
+	const int tid = threadIdx.x;
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
+	const int r0 = (int)chunk * F1_RCHUNK;
+	const int rc = (nb - r0) < F1_RCHUNK ? (nb - r0) : F1_RCHUNK;
+	const int4 cd = a.f1_chunks[chunk];
+	const int jlo = __builtin_amdgcn_readfirstlane(cd.x), jhi = __builtin_amdgcn_readfirstlane(cd.y);
+	const int plo = __builtin_amdgcn_readfirstlane(cd.z), phi = __builtin_amdgcn_readfirstlane(cd.w);
+	const int nent = (jhi - jlo) < F1P_CAPE ? (jhi - jlo) : F1P_CAPE;
+	const int npair = (phi - plo) < F1P_CAPP ? (phi - plo) : F1P_CAPP;
+
+	// ---- loads: everything of the chunk, coalesced, in flight together; then the gathers, from registers
+	constexpr int NE = F1P_CAPE / 256, NP = F1P_CAPP / 256;
+	int rbeg = 0, rend = 0, rdg = 0;  // this thread's row of the serial phase
+	if (tid < rc) {
+		rbeg = a.pat.browptr[r0 + tid];
+		rend = a.pat.browptr[r0 + tid + 1];
+		rdg = a.pat.diagind[r0 + tid];
+	}
+	int vpp0[NE], vpp1[NE], vd[NE], vlp[NP], vup[NP];
+	double va[NE];
+#pragma unroll
+	for (int i = 0; i < NE; i++) {
+		const int q = tid + 256 * i;
+		const bool p = q < nent;
+		vpp0[i] = p ? a.posptr[jlo + q] : 0;
+		vpp1[i] = p ? a.posptr[jlo + q + 1] : 0;
+		vd[i] = p ? a.f1_dcol[jlo + q] : -1;
+		va[i] = p ? a.avals[(long)jlo + q] : 0.0;
+	}
+#pragma unroll
+	for (int i = 0; i < NP; i++) {
+		const int q = tid + 256 * i;
+		vlp[i] = (q < npair) ? a.lowerp[plo + q] : 0;
+		vup[i] = (q < npair) ? a.upperp[plo + q] : 0;
+	}
+	double uv[NP], dv[NE];
+#pragma unroll
+	for (int i = 0; i < NP; i++)
+		uv[i] = (tid + 256 * i < npair) ? a.in[vup[i]] : 0.0;
+#pragma unroll
+	for (int i = 0; i < NE; i++)
+		dv[i] = vd[i] >= 0 ? a.in[vd[i]] : 1.0;
+#pragma unroll
+	for (int i = 0; i < NE; i++) {
+		const int q = tid + 256 * i;
+		if (q < nent) {
+			const int rel = vpp0[i] - plo;
+			s_pp[q] = rel < FAR ? (unsigned short)rel : FAR;
+			if (q == nent - 1) {
+				const int rel1 = vpp1[i] - plo;
+				s_pp[nent] = rel1 < FAR ? (unsigned short)rel1 : FAR;
+			}
+			// a lower entry without pairs is final right here
+			s_f[q] = (vd[i] >= 0 && vpp1[i] == vpp0[i]) ? va[i] / dv[i] : va[i];
+			s_dv[q] = dv[i];
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < NP; i++) {
+		const int q = tid + 256 * i;
+		if (q < npair) {
+			const int rel = vlp[i] - jlo;
+			s_lp[q] = (rel >= 0 && rel < nent) ? (unsigned short)rel : FAR;
+			s_uv[q] = uv[i];
+		}
+	}
+	__syncthreads();
+
+	// ---- one lane per row: the entries with pairs, in storage order (the reference's in-row order)
+	if (tid < rc) {
+		for (int jpos = rbeg; jpos < rend; jpos++) {
+			const int le = jpos - jlo;
+			if (le < nent) {
+				const int kb = s_pp[le], ke = s_pp[le + 1];
+				if (ke <= npair) {
+					if (kb == ke)
+						continue;  // no pairs: the matrix value (diagonal / upper) or a / u_jj (lower), already there
+					double s = s_f[le];
+					for (int k = kb; k < ke; k++) {
+						const unsigned short rel = s_lp[k];
+						const double lv = rel != FAR ? s_f[rel] : a.in[a.lowerp[plo + k]];
+						s -= lv * s_uv[k];
+					}
+					if (jpos < rdg)
+						s /= s_dv[le];
+					s_f[le] = s;
+					continue;
+				}
+			}
+			// beyond the staging capacity (rows much longer than a stencil's): from memory
+			const int col = a.pat.bcolind[jpos];
+			double s = a.avals[jpos];
+			const int kb = a.posptr[jpos], ke = a.posptr[jpos + 1];
+			for (int k = kb; k < ke; k++) {
+				const int lp = a.lowerp[k];
+				const int ll = lp - jlo;
+				const double lv = (ll >= 0 && ll < nent) ? s_f[ll] : a.in[lp];
+				s -= lv * a.in[a.upperp[k]];
+			}
+			if (jpos < rdg)
+				s /= a.in[a.pat.diagind[col]];
+			if (le < nent)
+				s_f[le] = s;
+			else
+				a.out[jpos] = s;
+		}
+	}
+	__syncthreads();
+
+#pragma unroll
+	for (int i = 0; i < NE; i++) {
+		const int q = tid + 256 * i;
+		if (q < nent)
+			a.out[(long)jlo + q] = s_f[q];
+	}
+}
+
 // ---- the exact scalar factorisation as one launch (round 2) ------------------------------------------------------
 // The scalar twin of sffactor4_kernel (kernels_factor4.hip, where the scheme and the row plans are described): one
 // LANE per row, the 256 rows of a workgroup from ONE dependency level, a row's plan (16 ints) and all its operands --
@@ -401,6 +564,20 @@ int launch_factor1_syncfree(const FactorArgs &a, LevelSchedule &ls, hipStream_t 
 	return ctl[1] == 0 ? 1 : -1;
 }
 
+// the plan of factor1p_kernel: dcol (nnz ints), chunks (factor1_plan_chunks(nbrows) int4)
+long factor1_plan_chunks(int nbrows)
+{
+	return ((long)nbrows + F1_RCHUNK - 1) / F1_RCHUNK;
+}
+
+void build_factor1_plan(const Pattern &pat, const int *posptr, int *dcol, int4 *chunks, hipStream_t s)
+{
+	if (pat.nbrows == 0)
+		return;
+	hipLaunchKernelGGL(f1_plan_kernel, dim3((unsigned)(((long)pat.nbrows + 255) / 256)), dim3(256), 0, s, pat, posptr, dcol, chunks);
+	BHIP_CHECK(hipGetLastError());
+}
+
 void set_factor1_enabled(int on)
 {
 	g_factor1_enabled = on;
@@ -416,7 +593,9 @@ bool launch_factor1(const FactorArgs &a, hipStream_t s)
 	if (!g_factor1_enabled || a.pat.bs != 1 || a.pat.nbrows == 0 || a.rows || !a.out)
 		return false;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F1_RCHUNK - 1) / F1_RCHUNK);
-	if (a.in == a.out)
+	if (a.in == a.out && !a.scale && a.f1_dcol && a.f1_chunks)
+		hipLaunchKernelGGL(factor1p_kernel, dim3(grid), dim3(256), 0, s, a);
+	else if (a.in == a.out)
 		hipLaunchKernelGGL(factor1_kernel<true>, dim3(grid), dim3(256), 0, s, a);
 	else
 		hipLaunchKernelGGL(factor1_kernel<false>, dim3(grid), dim3(256), 0, s, a);

@@ -276,6 +276,8 @@ void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream
 		return;
 	if (launch_sweepwr(a, part, post, dsrc, s))
 		return;
+	if (launch_sweep1(a, part, post, dsrc, s))
+		return;
 	switch (a.pat.bs) {
 	case 1: dispatch_layout<1>(a, part, post, dsrc, s); break;
 	case 2: dispatch_layout<2>(a, part, post, dsrc, s); break;

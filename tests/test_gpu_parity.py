@@ -461,6 +461,54 @@ def test_scalar_factor_kernels_agree(golden, case, usescale):
     p.close()
 
 
+@pytest.mark.parametrize("shape", ["short_rows", "poisson5", "dense_rows"])
+@pytest.mark.parametrize("init", [capi.INIT_F_ORIGINAL, capi.INIT_F_ZERO])
+def test_scalar_plan_factor_kernel_is_the_staged_one_bit_for_bit(shape, init):
+    """factor1p_kernel (precomputed plan, 16-bit LDS positions, parallel division of pair-free lower entries) against
+    factor1_kernel on matrices of at most 128 rows = ONE workgroup, where an in-place sweep is deterministic: every
+    sweep must give the same bits, non-finite early INIT_F_ZERO values included.  dense_rows has ~40 entries per
+    row: 2 400 entries against a staging capacity of 1 024, so most of the chunk takes the from-memory path, whose
+    results go to memory while other lanes read them (chaotic in both kernels): there the check is the fixed point."""
+    m = {"short_rows": lambda: W.random_bsr(100, 1, avg_offdiag=6, seed=2), "poisson5": lambda: W.poisson3d(5, 1),
+         "dense_rows": lambda: W.random_bsr(100, 1, avg_offdiag=40, seed=3)}[shape]()
+    assert m["nbrows"] <= 128
+    p = make_prec(m)
+    try:
+        for sweeps in (1, 2, 3, 7):
+            res = {}
+            for k in ("0", "1"):
+                capi.set_tuning("factor1plan=" + k)
+                p.ilu0_factorize(sweeps, init=init, mode=capi.ASYNC)
+                res[k] = p.get_iluvals()
+            if shape != "dense_rows":
+                assert np.array_equal(res["0"], res["1"], equal_nan=True), sweeps
+        exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+        for k in ("0", "1"):
+            capi.set_tuning("factor1plan=" + k)
+            p.ilu0_factorize(120, init=init, mode=capi.ASYNC)
+            assert rel(p.get_iluvals(), exact) < TOL_EXACT, k
+    finally:
+        capi.set_tuning("factor1plan=1")
+        p.close()
+
+
+@pytest.mark.parametrize("case", ["poisson16_csr", "random_csr", "2dcyl1_csr"])
+def test_scalar_plan_factor_kernel_reaches_the_exact_factor(golden, case):
+    """Many chunks: the two in-place scalar kernels reach the same exact factor (P3), from both initialisations."""
+    m = matrices(golden)[case]()
+    p = make_prec(m)
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    try:
+        for k in ("0", "1"):
+            capi.set_tuning("factor1plan=" + k)
+            for init, sweeps in ((capi.INIT_F_ORIGINAL, 60), (capi.INIT_F_ZERO, 120)):
+                p.ilu0_factorize(sweeps, init=init, mode=capi.ASYNC)
+                assert rel(p.get_iluvals(), exact) < TOL_EXACT, (k, init)
+    finally:
+        capi.set_tuning("factor1plan=1")
+        p.close()
+
+
 def test_warm_start_init_none(golden):
     m = matrices(golden)["poisson16_csr"]()
     p = make_prec(m)
@@ -566,6 +614,47 @@ def test_jacobi_and_sgs_match_oracle(golden, case):
             want = O.sgs_relax(m, gd, r, x0=x0, maxits=its, mode=O.JACOBI_SYNC)
             assert rel(x, want) < 1e-11
     p.close()
+
+
+@pytest.mark.parametrize("case", ["poisson16_csr", "random_csr", "poisson5_csr"])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 3])
+def test_scalar_lane_per_row_sweeps_match_oracle(golden, case, lanes):
+    """kernels_sweep1.hip (one lane per scalar row, 1 or 2 rows per lane in flight) and the general four-lanes-per-row
+    kernel (scalarlane=0) on every operator of the scalar path, synchronous sweeps against the oracle (P2), and the
+    in-place sweeps against the exact solve (P3).  random_csr has rows of 1..14 entries (empty lower / upper parts,
+    the remainder loop behind the four / eight straight-line entries) and 1001 rows (a ragged last chunk)."""
+    m = W.poisson3d(5, 1) if case == "poisson5_csr" else matrices(golden)[case]()
+    n = m["nbrows"]
+    r = W.rhs_vector(n)
+    x1 = 0.3 * np.sin(np.arange(n))
+    capi.set_tuning("scalarlane=%d" % lanes)
+    p = make_prec(m)
+    try:
+        assert rel(p.spmv(x1), O.spmv(m, x1)) < 1e-13
+        assert rel(p.gemv3(-1.5, x1, 0.25, r), O.gemv3(m, -1.5, x1, 0.25, r)) < 1e-13
+        load_exact_factor(p, m)
+        gf = p.get_iluvals()
+        for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+            for sweeps in (1, 3):
+                z = p.ilu0_apply(r, sweeps, init=init, mode=capi.JACOBI_SYNC)
+                assert rel(z, O.ilu0_apply(m, gf, r, sweeps, mode=O.JACOBI_SYNC, init=init)) < TOL_SYNC
+        exact = O.ilu0_apply(m, gf, r, 1, mode=O.GS_SERIAL)
+        assert rel(p.ilu0_apply(r, 60, mode=capi.ASYNC), exact) < TOL_EXACT
+        assert rel(p.ilu0_apply(r, 1, mode=capi.LEVEL), exact) < TOL_EXACT
+        p.jacobi_compute()
+        gd = p.get_dblocks()
+        assert rel(p.jacobi_apply(r), O.jacobi_apply(m, gd, r)) < 1e-13
+        for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+            z = p.sgs_apply(r, 3, init=init, mode=capi.JACOBI_SYNC)
+            assert rel(z, O.sgs_apply(m, gd, r, 3, mode=O.JACOBI_SYNC, init=init)) < TOL_SYNC
+        assert rel(p.sgs_apply(r, 80, mode=capi.ASYNC), O.sgs_apply(m, gd, r, 1, mode=O.GS_SERIAL, init=O.INIT_A_ZERO)) < TOL_EXACT
+        x = p.sgs_relax(r, x1.copy(), 4, mode=capi.JACOBI_SYNC)
+        assert rel(x, O.sgs_relax(m, gd, r, x0=x1, maxits=4, mode=O.JACOBI_SYNC)) < 1e-11
+        x = p.gs_relax(r, x1.copy(), 3, mode=capi.JACOBI_SYNC)
+        assert rel(x, O.gs_relax(m, gd, r, x0=x1, nsweeps=3, mode=O.JACOBI_SYNC)) < 1e-11
+    finally:
+        capi.set_tuning("scalarlane=1")
+        p.close()
 
 
 @pytest.mark.parametrize("case", ["2dcyl1_bs4_col", "2dcyl1_csr", "poisson16_bs4", "poisson12_bs5", "random_bs4"])
