@@ -1806,9 +1806,9 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)
 			g_factor1_plan = spec[12] != '0';
 		else if (spec && std::strncmp(spec, "scalarlane=", 11) == 0)
-			set_scalar_lane(spec[11] - '0');
+			set_scalar_lane(std::strcmp(spec + 11, "auto") == 0 ? -1 : spec[11] - '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)
-			set_sweep_unroll(spec[8] == '1' ? 1 : 0);
+			set_sweep_unroll(spec[8] == '1' ? 1 : (spec[8] == '2' ? 2 : 0));
 		else if (spec && std::strncmp(spec, "factorodd=", 10) == 0)
 			set_factorodd_enabled(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "relaxsplit=", 11) == 0)

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 	}
 }
 
-static int g_sweep_unroll = 0;  // 0 = default (2 where it applies), 1 = never unroll (measurements)
+static int g_sweep_unroll = 0;  // 0 = default (2 where it applies), 1 = never unroll (measurements), 2 = scalar rows too
 void set_sweep_unroll(int u)
 {
 	g_sweep_unroll = u;
@@ -223,7 +223,11 @@ static void dispatch_ops(const SweepArgs &a, Part part, Post post, DSrc dsrc, hi
 	if (part == P && post == Q && dsrc == D) {                                                   \
 		/* one block-row per wave (bs >= 5): two row steps in flight for the triangular sweeps */ \
 		constexpr int U = (Geo<BS>::G == 64 && (P == PART_LOWER || P == PART_UPPER)) ? 2 : 1;    \
-		if (BS == 1 && big && g_sweep_unroll != 1)                                               \
+		if (BS == 1 && big && g_sweep_unroll >= 2)                                               \
+			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, (BS == 1 ? 4 : 1), BS == 1>), dim3(gridbig), dim3(256), 0, s, a); \
+		else if (BS == 1 && g_sweep_unroll >= 2)                                                 \
+			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, (BS == 1 ? 2 : 1)>), dim3(grid), dim3(256), 0, s, a); \
+		else if (BS == 1 && big && g_sweep_unroll != 1)                                          \
 			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, U, BS == 1>), dim3(gridbig), dim3(256), 0, s, a); \
 		else if (g_sweep_unroll == 1)                                                            \
 			hipLaunchKernelGGL((sweep_kernel<BS, RM, P, Q, D, 1>), dim3(grid), dim3(256), 0, s, a); \

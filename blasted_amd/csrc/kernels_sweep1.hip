@@ -28,9 +28,13 @@ namespace {
 
 constexpr int SWEEP1_MAX_ROW = 16;
 
-template <int PART, int POST, int DSRC, int NR>
-__global__ __launch_bounds__(256) void sweep1_kernel(const SweepArgs a)
+// SEQ (in-place sweeps): the workgroup is ONE wave that takes its 256 rows 64 at a time, each step after the stores
+// of the step before -- the same bytes in flight per wave, but inside a chunk the sweep is in order at 64-row
+// granularity instead of 256 rows read at once by four waves.
+template <int PART, int POST, int DSRC, int NR, bool SEQ>
+__global__ __launch_bounds__(SEQ ? 64 : 256) void sweep1_kernel(const SweepArgs a)
 {
+	static_assert(!SEQ || NR == 1, "the sequential form takes one row per lane and step");
 	constexpr bool DIAG_FIRST = PART == PART_UPPER && (DSRC == D_VALS_DIAG || DSRC == D_RECIP_DIAG);
 	constexpr int KFIX = (PART == PART_NONE) ? 0 : ((PART == PART_ALL || PART == PART_OFFDIAG) ? 8 : 4);
 	constexpr int KF = KFIX > 0 ? KFIX : 1;
@@ -49,11 +53,13 @@ __global__ __launch_bounds__(256) void sweep1_kernel(const SweepArgs a)
 	const double *const __restrict__ vals = a.vals;
 	const double *const xin = a.xin;
 
+#pragma unroll 1
+	for (int seq = 0; seq < (SEQ ? 4 : 1); seq++) {
 	bool ok[NR];
 	int lr[NR], jbeg[NR], jend[NR], dg[NR];
 #pragma unroll
 	for (int q = 0; q < NR; q++) {
-		const int ls = q * 256 + tid;  // position in sweep order
+		const int ls = SEQ ? seq * 64 + tid : q * 256 + tid;  // position in sweep order
 		ok[q] = ls < rc;
 		lr[q] = ok[q] ? (a.descending ? rc - 1 - ls : ls) : 0;
 		jbeg[q] = jend[q] = dg[q] = 0;
@@ -145,22 +151,31 @@ __global__ __launch_bounds__(256) void sweep1_kernel(const SweepArgs a)
 		if (ok[q])
 			a.xout[r0 + lr[q]] = out;
 	}
+	}
 }
 
-// tuning "scalarlane=0|1|2|3": 0 = the general kernel, 1 / 2 = this kernel with one / two rows per lane, 3 = as 1
-// and for the matrix-vector product too
+// tuning "scalarlane=auto|0|1|2|3|4": 0 = the general kernel everywhere, 1 / 2 = this kernel with one / two rows per
+// lane, 3 = as 1 and for the whole-row operators too, 4 = the one-wave sequential form; auto (-1, default) = this
+// kernel (one row per lane) for sweeps that write a SECOND buffer -- synchronous / deterministic sweeps, where only
+// speed differs (256^3: 0.43 against 0.53 ms per L+U pair, 0.71 against 0.57 of the HBM peak) -- and the general
+// kernel for IN-PLACE sweeps.  In place the lane-per-row form is the faster sweep but the worse preconditioner: it
+// has 2 048 rows per CU in flight instead of 512, so more of a sweep reads the iterate of the sweep before
+// (256^3, 3+3 sweeps: distance to the exact solve 0.244 against 0.212), and inside the reference's flexible solver
+// that costs more than the sweep gains -- GCR(30) on 160^3 with 3 sweeps per application: 603-607 iterations / 640-650
+// ms with the general kernel, 855-882 / 834-863 ms with one lane per row, 720-722 / 731-734 ms with the sequential
+// form; with 5 sweeps all three meet at 478-524 iterations / 605-622 ms (profiles/r03_scalar_kernels.txt).
 int g_scalar_lane = [] {
 	const char *e = std::getenv("BLASTED_HIP_SCALARLANE");
-	return e ? std::atoi(e) : 1;
+	return e ? std::atoi(e) : -1;
 }();
 
-template <int NR>
+template <int NR, bool SEQ>
 bool dispatch1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + 256 * NR - 1) / (256 * NR));
 #define BHIP_CASE1(P, Q, D)                                                                    \
 	if (part == P && post == Q && dsrc == D) {                                                 \
-		hipLaunchKernelGGL((sweep1_kernel<P, Q, D, NR>), dim3(grid), dim3(256), 0, s, a);      \
+		hipLaunchKernelGGL((sweep1_kernel<P, Q, D, NR, SEQ>), dim3(grid), dim3(SEQ ? 64 : 256), 0, s, a); \
 		return true;                                                                           \
 	}
 	BHIP_CASE1(PART_LOWER, POST_SUB, D_NONE)
@@ -186,12 +201,16 @@ bool launch_sweep1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStrea
 {
 	if (a.pat.bs != 1 || g_scalar_lane == 0 || a.pat.max_row_len > SWEEP1_MAX_ROW)
 		return false;
-	// whole rows (SpMV / gemv3): a lane's seven entries are 84 bytes apart from its neighbour's, seven loads a wave
-	// each spread over 28 cache lines -- measured SLOWER than the general kernel from 200^3 on (256^3: 0.50 against
-	// 0.38 ms; 128^3 equal), so the product keeps the general kernel unless asked for ("scalarlane=3")
-	if (part == PART_ALL && g_scalar_lane != 3)
+	// whole rows (SpMV / gemv3, relaxation): a lane's seven entries are 84 bytes apart from its neighbour's, seven
+	// loads a wave each spread over 28 cache lines -- measured SLOWER than the general kernel from 200^3 on (256^3:
+	// product 0.50 against 0.38 ms, relaxation step 1.05 against 0.86 ms; 128^3 equal), so these keep the general
+	// kernel unless asked for ("scalarlane=3")
+	if ((part == PART_ALL || part == PART_OFFDIAG) && g_scalar_lane != 3)
 		return false;
-	const bool done = g_scalar_lane == 2 ? dispatch1<2>(a, part, post, dsrc, s) : dispatch1<1>(a, part, post, dsrc, s);
+	if (g_scalar_lane < 0 && a.xin == a.xout && part != PART_NONE)
+		return false;
+	const bool done = g_scalar_lane == 2 ? dispatch1<2, false>(a, part, post, dsrc, s)
+	                  : (g_scalar_lane == 4 ? dispatch1<1, true>(a, part, post, dsrc, s) : dispatch1<1, false>(a, part, post, dsrc, s));
 	if (done)
 		BHIP_CHECK(hipGetLastError());
 	return done;

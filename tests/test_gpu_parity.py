@@ -617,7 +617,7 @@ def test_jacobi_and_sgs_match_oracle(golden, case):
 
 
 @pytest.mark.parametrize("case", ["poisson16_csr", "random_csr", "poisson5_csr"])
-@pytest.mark.parametrize("lanes", [0, 1, 2, 3])
+@pytest.mark.parametrize("lanes", ["auto", 0, 1, 2, 3, 4])
 def test_scalar_lane_per_row_sweeps_match_oracle(golden, case, lanes):
     """kernels_sweep1.hip (one lane per scalar row, 1 or 2 rows per lane in flight) and the general four-lanes-per-row
     kernel (scalarlane=0) on every operator of the scalar path, synchronous sweeps against the oracle (P2), and the
@@ -627,7 +627,7 @@ def test_scalar_lane_per_row_sweeps_match_oracle(golden, case, lanes):
     n = m["nbrows"]
     r = W.rhs_vector(n)
     x1 = 0.3 * np.sin(np.arange(n))
-    capi.set_tuning("scalarlane=%d" % lanes)
+    capi.set_tuning("scalarlane=%s" % lanes)
     p = make_prec(m)
     try:
         assert rel(p.spmv(x1), O.spmv(m, x1)) < 1e-13
@@ -653,7 +653,7 @@ def test_scalar_lane_per_row_sweeps_match_oracle(golden, case, lanes):
         x = p.gs_relax(r, x1.copy(), 3, mode=capi.JACOBI_SYNC)
         assert rel(x, O.gs_relax(m, gd, r, x0=x1, nsweeps=3, mode=O.JACOBI_SYNC)) < 1e-11
     finally:
-        capi.set_tuning("scalarlane=1")
+        capi.set_tuning("scalarlane=auto")
         p.close()
 
 

@@ -50,8 +50,11 @@ def main():
         p.ilu0_factorize(30)
         exact = p.ilu0_apply(r, 1, mode=capi.LEVEL).clone()
         p.jacobi_compute()
-        for lanes in (0, 1, 2):
+        for lanes, unr in ((0, 0), (1, 0), (4, 0)):
             capi.set_tuning("scalarlane=%d" % lanes)
+            capi.set_tuning("gunroll=%d" % unr)
+            if unr:
+                print("(general kernel with 2 / 4 row steps in flight: gunroll=2)")
             for mode, name in ((capi.ASYNC, "async"), (capi.JACOBI_SYNC, "sync")):
                 t2 = timed(lambda: p.ilu0_apply(r, 2, mode=mode, out=z), 10)
                 t12 = timed(lambda: p.ilu0_apply(r, 12, mode=mode, out=z), 10)
@@ -71,7 +74,8 @@ def main():
             ts = timed(lambda: p.spmv(r, out=z), 20)
             print("n=%d scalarlane=%d SGS sync sweep pair %.4f ms = %.3f of peak; SpMV %.4f ms = %.3f of peak" % (
                 n, lanes, per * 1e3, ab["sgs_pair"] / per / PEAK, ts * 1e3, ab["spmv"] / ts / PEAK), flush=True)
-        capi.set_tuning("scalarlane=1")
+        capi.set_tuning("scalarlane=auto")
+        capi.set_tuning("gunroll=0")
         p.close()
         del m, r, z
         torch.cuda.empty_cache()
