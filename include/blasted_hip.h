@@ -244,7 +244,12 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * relaxation passes too); "latestore=2" (default) / "0|1|4": the in-place bs=4 triangular sweeps store a workgroup's
  * rows once, with 2 (1, 4) row steps of a wave in flight, or step by step (0) -- bs=8: any non-zero value = stored
  * once (environment: BLASTED_HIP_LATESTORE); "invertrow=1" (default) / "0": diagonal blocks of size 5..8 inverted
- * by eight lanes per block or by one thread per block.  Measurement hooks that give WRONG results (timing
+ * by eight lanes per block or by one thread per block; "scalarlane=auto" (default) / "0|1|2|3|4": scalar (CSR)
+ * triangular sweeps with one lane per row when they write a second buffer and the general kernel in place (auto),
+ * the general kernel everywhere (0), one lane per row everywhere with one / two rows per lane (1 / 2), for the
+ * whole-row operators too (3), or its one-wave sequential form (4) (environment: BLASTED_HIP_SCALARLANE);
+ * "factor1plan=1" (default) / "0": scalar in-place factorisation sweeps on the per-pattern plan or with the round-2
+ * kernel; "gunroll=2": the general scalar kernel with 2 / 4 row steps in flight.  Measurement hooks that give WRONG results (timing
  * experiments only): "levelnowait=1" (exact passes with nobody waiting), "gatherprobe=1" (odd block sizes gather
  * their own row), "gatherprobe=2|3" (store probes of the interleaved sweeps). */
 int blasted_hip_set_tuning(const char *spec);
