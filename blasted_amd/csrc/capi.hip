@@ -1838,7 +1838,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "factor4=", 8) == 0)
 			set_factor4_enabled(spec[8] == 's' ? 10 + (spec[9] - '0') : (spec[8] != '0'));
 		else if (spec && std::strncmp(spec, "factor8=", 8) == 0)
-			set_factor8_enabled(spec[8] != '0');
+			set_factor8_enabled(spec[8] == '2' ? 2 : (spec[8] != '0'));
 		else
 			set_sweepw_variant(spec);
 	});

@@ -69,6 +69,13 @@ __device__ __forceinline__ double inverse_b_layout(const double v, const int k, 
 	return cof * (1.0 / det);
 }
 
+// Round 3, tried and removed: an up-front row path as in kernels_factor8.hip (a wave whose four rows are stencil-like
+// requests their matrix blocks, the u_jj of their lower blocks and the u_kj of their pairs together -- 5 KB in flight
+// instead of ~1 KB -- and hands finished lower blocks on in registers instead of reading them back behind their
+// store).  Verified against the exact factor, 88 registers (five waves per SIMD instead of eight), and SLOWER:
+// 128^3 0.853 -> 0.922 ms, 256^3 6.86 -> 7.41 ms per sweep.  At bs=8 the same change is worth 27 %; here the sweep
+// already moves 36.6 GB in 6.9 ms = 5.3 TB/s of read+write traffic, near what a copy reaches on these boxes
+// (profiles/r01l_stream_ceiling.txt: 5.8-6.3 TB/s), so there is no latency left to hide and the lost waves cost.
 __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 {
 	__shared__ int s_rp[F4_RCHUNK + 1];

@@ -42,6 +42,9 @@ __device__ __forceinline__ double mfma444(const double a, const double b, const 
 	return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+constexpr int F8_MW = 4, F8_ML = 3, F8_MP = 4;  // the fast path's window: blocks with work, lower ones, pairs
+
+template <bool INPLACE_FAST>
 __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const double *dinv)
 {
 	__shared__ int s_rp[F8_RCHUNK + 1];
@@ -76,6 +79,105 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 		const int irow = r0 + ls;
 		const int jbeg = __builtin_amdgcn_readfirstlane(s_rp[ls]);
 		const int jend = __builtin_amdgcn_readfirstlane(s_rp[ls + 1]);
+
+		// ---- round 3: stencil-like rows of an in-place sweep, everything requested up front.  The loop below takes a
+		// row block by block: a block's loads go out after the store of the block before (in place, `in` and `out`
+		// alias), and a pair's l_ik -- a lower block of THIS row, stored a moment ago -- is read back from memory
+		// behind that store.  A row whose work lies in its first F8_MW blocks (at most F8_ML lower ones, at most
+		// F8_MP pairs; the blocks behind are pair-less upper blocks that the sweep leaves alone) instead requests
+		// its matrix blocks, the inverses for its lower blocks and the u_kj of all its pairs together (8 KB in
+		// flight for an interior 7-point row), then runs the blocks in storage order out of registers, handing each
+		// finished lower block on in A-operand layout (the two shuffles a re-read would have saved are the price).
+		// Same operations on the same operands in the same order as the loop below.
+		if (INPLACE_FAST && jend - jlo <= F8_CAPB) {
+			bool valid[F8_MW], work[F8_MW], low[F8_MW];
+			int col[F8_MW], kb[F8_MW], ke[F8_MW];
+			bool fast = true;
+#pragma unroll
+			for (int e = 0; e < F8_MW; e++) {
+				const int jpos = jbeg + e;
+				valid[e] = jpos < jend;
+				const int bidx = valid[e] ? jpos - jlo : 0;
+				col[e] = __builtin_amdgcn_readfirstlane(s_col[bidx]);
+				kb[e] = __builtin_amdgcn_readfirstlane(s_pp[bidx]);
+				ke[e] = __builtin_amdgcn_readfirstlane(s_pp[bidx + 1]);
+				work[e] = valid[e] && !(a.skip_fixed && col[e] > irow && ke[e] == kb[e]);
+				low[e] = work[e] && col[e] < irow;
+				if (low[e] && e >= F8_ML)
+					fast = false;
+			}
+			// the blocks behind the window must all be left alone
+			for (int jpos = jbeg + F8_MW; jpos < jend; jpos++) {
+				const int bidx = jpos - jlo;
+				const int c = __builtin_amdgcn_readfirstlane(s_col[bidx]);
+				const int k0 = __builtin_amdgcn_readfirstlane(s_pp[bidx]), k1 = __builtin_amdgcn_readfirstlane(s_pp[bidx + 1]);
+				if (!(a.skip_fixed && c > irow && k1 == k0))
+					fast = false;
+			}
+			const int pb = __builtin_amdgcn_readfirstlane(s_pp[jbeg - jlo]);
+			const int wend = (jbeg + F8_MW < jend ? jbeg + F8_MW : jend) - jlo;
+			const int np = __builtin_amdgcn_readfirstlane(s_pp[wend]) - pb;
+			if (np > F8_MP || pb - plo + np > F8_CAPP)
+				fast = false;
+			if (fast) {
+				double av[F8_MW], dv[F8_ML][2], uo[F8_MP][2], lres[F8_ML][2];
+				int slot[F8_MP];
+#pragma unroll
+				for (int e = 0; e < F8_MW; e++)
+					av[e] = work[e] ? a.avals[(long)(jbeg + e) * 64 + offD] : 0.0;
+#pragma unroll
+				for (int e = 0; e < F8_ML; e++) {
+					dv[e][0] = low[e] ? dinv[(long)col[e] * 64 + offB0] : 0.0;
+					dv[e][1] = low[e] ? dinv[(long)col[e] * 64 + offB1] : 0.0;
+					lres[e][0] = lres[e][1] = 0.0;
+				}
+#pragma unroll
+				for (int q = 0; q < F8_MP; q++) {
+					const int pidx = q < np ? pb - plo + q : 0;
+					const int up = __builtin_amdgcn_readfirstlane(s_up[pidx]);
+					slot[q] = __builtin_amdgcn_readfirstlane(s_lp[pidx]) - jbeg;
+					uo[q][0] = q < np ? a.in[(long)up * 64 + offB0] : 0.0;
+					uo[q][1] = q < np ? a.in[(long)up * 64 + offB1] : 0.0;
+				}
+				if (a.scale) {
+#pragma unroll
+					for (int e = 0; e < F8_MW; e++)
+						if (work[e])
+							av[e] *= a.scale[(long)irow * 8 + 4 * ti + k] * a.scale[(long)col[e] * 8 + 4 * tj + m];
+				}
+#pragma unroll
+				for (int e = 0; e < F8_MW; e++) {
+					if (!work[e])
+						continue;
+					double acc = 0.0;
+#pragma unroll
+					for (int q = 0; q < F8_MP; q++) {
+						if (q < np && pb + q >= kb[e] && pb + q < ke[e]) {
+							double l0 = lres[0][0], l1 = lres[0][1];
+#pragma unroll
+							for (int t = 1; t < F8_ML; t++) {
+								l0 = slot[q] == t ? lres[t][0] : l0;
+								l1 = slot[q] == t ? lres[t][1] : l1;
+							}
+							acc = mfma444(l0, uo[q][0], acc);
+							acc = mfma444(l1, uo[q][1], acc);
+						}
+					}
+					double res = av[e] - acc;
+					if (e < F8_ML && low[e]) {
+						const double sa0 = __shfl(res, srcA0, 64), sa1 = __shfl(res, srcA1, 64);
+						double prod = mfma444(sa0, dv[e][0], 0.0);
+						prod = mfma444(sa1, dv[e][1], prod);
+						res = prod;
+						lres[e][0] = __shfl(res, srcA0, 64);
+						lres[e][1] = __shfl(res, srcA1, 64);
+					}
+					a.out[(long)(jbeg + e) * 64 + offD] = res;
+				}
+				continue;
+			}
+		}
+
 		for (int jpos = jbeg; jpos < jend; jpos++) {
 			const int bidx = jpos - jlo;
 			int col, kb, ke;
@@ -157,7 +259,11 @@ bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s)
 		return false;
 	launch_invert_diag_blocks(a.pat, a.in, 1, dinv_scratch, 0, s);
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F8_RCHUNK - 1) / F8_RCHUNK);
-	hipLaunchKernelGGL(factor8_kernel, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+	// (tuning "factor8=2": in-place sweeps with the block-by-block loop only, the round-2 kernel)
+	if (a.in == a.out && g_factor8_enabled != 2)
+		hipLaunchKernelGGL(factor8_kernel<true>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+	else
+		hipLaunchKernelGGL(factor8_kernel<false>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
 	BHIP_CHECK(hipGetLastError());
 	return true;
 }

@@ -509,6 +509,41 @@ def test_scalar_plan_factor_kernel_reaches_the_exact_factor(golden, case):
         p.close()
 
 
+@pytest.mark.parametrize("bs", [8])
+@pytest.mark.parametrize("shape", ["poisson9", "poisson5", "random_short", "random_long"])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_block_in_place_factor_row_path_reaches_the_exact_factor(bs, shape, usescale):
+    """The up-front row path of factor8_kernel (in place: a row's matrix blocks, the inverses for its lower blocks and
+    the u_kj of its pairs requested together, finished lower blocks handed on in registers) against the
+    block-by-block loop (factor8=2) and the general kernel (factor8=0): all reach the exact factor from both
+    initialisations.  random_short mixes rows that fit the path's window (<= 3 lower blocks, <= 4 pairs) with rows
+    that do not; random_long has none that fit.  (The same path at bs=4 was measured slower and removed.)"""
+    m = {"poisson9": lambda: W.poisson3d(9, bs), "poisson5": lambda: W.poisson3d(5, bs),
+         "random_short": lambda: W.random_bsr(400, bs, avg_offdiag=3, seed=21),
+         "random_long": lambda: W.random_bsr(150, bs, avg_offdiag=14, seed=22)}[shape]()
+    if usescale and shape.startswith("random"):
+        pytest.skip("random test matrices may have negative diagonal entries (sqrt)")
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL, usescale=usescale)["iluvals"]
+    p = make_prec(m)
+    try:
+        for k in ("1", "2", "0"):
+            capi.set_tuning("factor%d=%s" % (bs, k))
+            for init, sweeps in ((capi.INIT_F_ORIGINAL, 60), (capi.INIT_F_ZERO, 120)):
+                p.ilu0_factorize(sweeps, init=init, usescale=usescale, mode=capi.ASYNC)
+                assert rel(p.get_iluvals(), exact) < TOL_EXACT, (k, init)
+        # one sweep from the same start: the three kernels do the same arithmetic on iterates that differ only by
+        # which neighbours' updates a row happened to see
+        res = {}
+        for k in ("1", "2"):
+            capi.set_tuning("factor%d=%s" % (bs, k))
+            p.ilu0_factorize(1, init=capi.INIT_F_ORIGINAL, usescale=usescale, mode=capi.ASYNC)
+            res[k] = p.get_iluvals()
+        assert np.all(np.isfinite(res["1"])) and rel(res["1"], res["2"]) < 0.2
+    finally:
+        capi.set_tuning("factor%d=1" % bs)
+        p.close()
+
+
 def test_warm_start_init_none(golden):
     m = matrices(golden)["poisson16_csr"]()
     p = make_prec(m)
