@@ -544,6 +544,38 @@ def test_block_in_place_factor_row_path_reaches_the_exact_factor(bs, shape, uses
         p.close()
 
 
+@pytest.mark.parametrize("shape", ["poisson12_bs5", "poisson8_bs7", "random_bs5", "random_bs7", "random_long_bs5"])
+def test_odd_block_factor_kernels_agree(shape):
+    """factorodd_kernel (16 / 32 lanes per block-row, products through LDS tiles) against the general kernel
+    (factorodd=0): synchronous sweeps match the oracle's, in place both reach the exact factor from both
+    initialisations.  random_long_bs5 has ~30 blocks a row and many pairs per block."""
+    m = {"poisson12_bs5": lambda: W.poisson3d(12, 5), "poisson8_bs7": lambda: W.poisson3d(8, 7),
+         "random_bs5": lambda: W.random_bsr(1500, 5, avg_offdiag=8, seed=12345),
+         "random_bs7": lambda: W.random_bsr(500, 7, avg_offdiag=6, seed=5),
+         "random_long_bs5": lambda: W.random_bsr(300, 5, avg_offdiag=30, seed=9)}[shape]()
+    nlev = int(W.dependency_levels(m).max()) + 1
+    p = make_prec(m)
+    res = {}
+    try:
+        for k in ("1", "0"):
+            capi.set_tuning("factorodd=" + k)
+            p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)
+            res[k] = p.get_iluvals()
+            p.ilu0_factorize(90, mode=capi.ASYNC)
+            res[k + "x"] = p.get_iluvals()
+            # (from a zero factor the finite values advance at least one dependency level per sweep)
+            p.ilu0_factorize(max(90, 2 * nlev + 2), init=capi.INIT_F_ZERO, mode=capi.ASYNC)
+            res[k + "z"] = p.get_iluvals()
+    finally:
+        capi.set_tuning("factorodd=1")
+        p.close()
+    want = O.ilu0_factorize(m, None, 3, mode=O.JACOBI_SYNC)["iluvals"]
+    exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
+    assert rel(res["1"], want) < TOL_SYNC and rel(res["0"], want) < TOL_SYNC
+    for k in ("1x", "0x", "1z", "0z"):
+        assert rel(res[k], exact) < TOL_EXACT, k
+
+
 def test_warm_start_init_none(golden):
     m = matrices(golden)["poisson16_csr"]()
     p = make_prec(m)

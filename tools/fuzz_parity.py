@@ -41,7 +41,8 @@ def main():
                                                      "interleave", "sweepodd", "sweepwr", "factorodd",
                                                      "factor4", "factor8", "gunroll")}
         tune["factor1"] = int(rng.integers(0, 2))
-        tune["factor8"] = int(rng.choice([0, 1, 1, 2]))            # generic / up-front row path / block-by-block loop
+        tune["factor8"] = int(rng.choice([0, 1, 1, 2]))
+        tune["factorodd"] = int(rng.choice([0, 1, 1, 2]))        # general / staged, batched operands / round-2 kernel            # generic / up-front row path / block-by-block loop
         tune["level"] = str(rng.choice(["syncfree", "syncfree", "launch"]))
         tune["copies"] = str(rng.choice(["one", "both"]))
         tune["xcdsuper"] = int(rng.choice([1, 4, 16, 64]))
