@@ -1803,6 +1803,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
 			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
+		else if (spec && std::strncmp(spec, "factorprobe=", 12) == 0)
+			set_factor_probe(spec[12] - '0');
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)
 			g_factor1_plan = spec[12] != '0';
 		else if (spec && std::strncmp(spec, "scalarlane=", 11) == 0)

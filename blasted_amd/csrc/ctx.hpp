@@ -193,6 +193,7 @@ void set_factor8_enabled(int on);
 // kernels_factorodd.hip (bs=5/7 column-major factorisation sweep in the 16-byte pair layout)
 bool launch_factorodd(const FactorArgs &a, double *dinv_scratch, hipStream_t s);
 void set_factorodd_enabled(int on);
+void set_factor_probe(int v);
 // kernels_factor.hip
 void launch_factor_sweep(const FactorArgs &a, hipStream_t s);
 int launch_factor_levels(FactorArgs a, const LevelSchedule &ls, hipStream_t s);

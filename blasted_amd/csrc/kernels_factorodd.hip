@@ -22,7 +22,10 @@ namespace {
 typedef double fd2_t __attribute__((ext_vector_type(2)));
 typedef fd2_t fd2u_t __attribute__((aligned(8)));
 
-template <int BS>
+// PROBE (measurements only, tuning "factorprobe=1..5", WRONG results): 1 = the block products skip the LDS tiles (each
+// lane multiplies its own entries), 2 = the operand blocks of the pairs are not loaded (the matrix block stands in),
+// 3 = no pairs at all and no store, 4 = no pairs, no matrix block, no inverse (indices + store), 5 = indices only
+template <int BS, int PROBE = 0>
 __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, const double *__restrict__ dinv)
 {
 	static_assert(BS == 5 || BS == 7, "odd block sizes 5, 7");
@@ -53,6 +56,11 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 
 	// out(r,c) = sum_m x(r,m) y(m,c) for this lane's two entries; x, y given as this lane's entry pairs
 	auto gemm = [&](const fd2_t x, const fd2_t y, double &oA, double &oB) {
+		if (PROBE == 1) {
+			oA = x.x * y.x;
+			oB = x.y * y.y;
+			return;
+		}
 		if (actA) {
 			tl[eA] = x.x;
 			tu[eA] = y.x;
@@ -80,16 +88,21 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 			continue;  // an upper block without pairs: the sweep before has stored its value, a_ij
 		fd2_t s;
 		s.x = s.y = 0.0;
-		if (actB)
+		if (actB && PROBE < 4)
 			s = *reinterpret_cast<const fd2u_t *>(a.avals + (long)jpos * BS2 + boff);
+		if (PROBE >= 4)
+			s.x = s.y = (double)(col + kend);
 		if (a.scale && actB) {
 			s.x *= a.scale[(long)irow * BS + rA] * a.scale[(long)col * BS + cA];
 			s.y *= a.scale[(long)irow * BS + rB] * a.scale[(long)col * BS + cB];
 		}
-		for (int k = kbeg; k < kend; k++) {
+		for (int k = kbeg; k < (PROBE >= 3 ? kbeg : kend); k++) {
 			fd2_t lv, uv;
 			lv.x = lv.y = uv.x = uv.y = 0.0;
-			if (actB) {
+			if (PROBE == 2) {
+				lv = s;
+				uv = s;
+			} else if (actB) {
 				lv = *reinterpret_cast<const fd2u_t *>(a.in + (long)a.lowerp[k] * BS2 + boff);
 				uv = *reinterpret_cast<const fd2u_t *>(a.in + (long)a.upperp[k] * BS2 + boff);
 			}
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 			s.x -= pA;
 			s.y -= pB;
 		}
-		if (irow > col) {
+		if (irow > col && PROBE < 4) {
 			fd2_t dv;
 			dv.x = dv.y = 0.0;
 			if (actB)
@@ -109,7 +122,10 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 			s.y = pB;
 		}
 		double *const dst = a.out + (long)jpos * BS2 + boff;
-		if (actA)
+		if (PROBE == 3 || PROBE == 5) {
+			if (s.x == 1.2345e300 && actA)  // never: keeps the work alive without the store
+				*dst = s.y;
+		} else if (actA)
 			*reinterpret_cast<fd2u_t *>(dst) = s;
 		else if (actB)
 			dst[1] = s.y;  // last lane: only the block's last entry is its own
@@ -117,8 +133,14 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 }
 
 int g_factorodd_enabled = -1;
+int g_factor_probe = 0;
 
 }  // namespace
+
+void set_factor_probe(int v)
+{
+	g_factor_probe = v;
+}
 
 static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipStream_t s);
 
@@ -153,7 +175,18 @@ static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipSt
 		return;
 	if (a.pat.bs == 5) {
 		const unsigned grid = (unsigned)((n + 15) / 16);
-		hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, dinv);
+		if (g_factor_probe == 1)
+			hipLaunchKernelGGL((factorodd_kernel<5, 1>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else if (g_factor_probe == 2)
+			hipLaunchKernelGGL((factorodd_kernel<5, 2>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else if (g_factor_probe == 3)
+			hipLaunchKernelGGL((factorodd_kernel<5, 3>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else if (g_factor_probe == 4)
+			hipLaunchKernelGGL((factorodd_kernel<5, 4>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else if (g_factor_probe == 5)
+			hipLaunchKernelGGL((factorodd_kernel<5, 5>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else
+			hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, dinv);
 	} else {
 		const unsigned grid = (unsigned)((n + 7) / 8);
 		hipLaunchKernelGGL(factorodd_kernel<7>, dim3(grid), dim3(256), 0, s, a, dinv);
