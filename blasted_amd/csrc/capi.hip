@@ -1807,6 +1807,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_factor_probe(spec[12] - '0');
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)
 			g_factor1_plan = spec[12] != '0';
+		else if (spec && std::strncmp(spec, "scalarstage=", 12) == 0)
+			set_scalar_stage(spec[12] != '0');
 		else if (spec && std::strncmp(spec, "scalarlane=", 11) == 0)
 			set_scalar_lane(std::strcmp(spec + 11, "auto") == 0 ? -1 : spec[11] - '0');
 		else if (spec && std::strncmp(spec, "gunroll=", 8) == 0)

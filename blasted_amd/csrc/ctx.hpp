@@ -153,6 +153,7 @@ void set_sweepwr_enabled(int on);
 // kernels_sweep1.hip (scalar CSR with short rows, one lane per row; false = not covered)
 bool launch_sweep1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_scalar_lane(int v);
+void set_scalar_stage(int v);
 // kernels_sweepodd.hip (tuned bs=3/5/7 column-major path; false = not covered)
 bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s);
 void set_sweepodd_enabled(int on);

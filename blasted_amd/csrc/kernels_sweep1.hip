@@ -154,6 +154,90 @@ __global__ __launch_bounds__(SEQ ? 64 : 256) void sweep1_kernel(const SweepArgs 
 	}
 }
 
+// ---- whole-row operators (product / gemv3, relaxation) on short rows: products staged through LDS ------------------
+// One lane per row reading its own seven entries is slower than the general kernel here (above).  This form keeps
+// every global access coalesced: the workgroup's threads load the chunk's entries and column indices in storage
+// order (thread q takes entries q, q + 256, ...), gather x for THEIR entries straight from registers, multiply, and
+// leave the products in LDS; after one barrier a lane sums its row's products in storage order (the reference's
+// order), applies the operator and stores.  LDS holds one double per entry (14 KB for 256 7-point rows), the whole
+// chunk -- 21 KB of entries and indices, then 14 KB of gathers -- is in flight at once, two memory round trips per
+// chunk.  The 256 rows of a chunk are read before any is stored, so in place (asynchronous relaxation) the general
+// kernel stays; this one takes the product and the relaxation passes into a second buffer.  Rows of at most
+// SWEEP1S_MAX_ROW entries (host-side check: a chunk then fits the staging capacity).
+constexpr int SWEEP1S_MAX_ROW = 8;
+constexpr int SWEEP1S_CAP = 256 * SWEEP1S_MAX_ROW;
+
+template <int PART, int POST, int DSRC>
+__global__ __launch_bounds__(256) void sweep1s_kernel(const SweepArgs a)
+{
+	static_assert(PART == PART_ALL || PART == PART_OFFDIAG, "whole-row operators");
+	__shared__ double s_prod[SWEEP1S_CAP];
+
+	const int tid = threadIdx.x;
+	const int nb = a.pat.nbrows;
+	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x, (unsigned)(a.xcd_shift < 0 ? 4 : a.xcd_shift));
+	const long lin0 = (long)chunk * 256;
+	const int rc = (int)((nb - lin0) < 256 ? (nb - lin0) : 256);
+	const int r0 = a.descending ? (int)(nb - lin0 - rc) : (int)lin0;  // rows [r0, r0 + rc)
+	const int jlo = __builtin_amdgcn_readfirstlane(a.pat.browptr[r0]);
+	const int jhi = __builtin_amdgcn_readfirstlane(a.pat.browptr[r0 + rc]);
+	const int nent = jhi - jlo;  // <= SWEEP1S_CAP (launcher)
+
+	// this lane's row (order inside a chunk does not matter: nothing is stored before everything is read)
+	const bool ok = tid < rc;
+	int jbeg = 0, jend = 0, dg = -1;
+	double rv = 0.0, d = 0.0;
+	if (ok) {
+		jbeg = a.pat.browptr[r0 + tid];
+		jend = a.pat.browptr[r0 + tid + 1];
+		if (PART == PART_OFFDIAG)
+			dg = a.pat.diagind[r0 + tid];
+		if (a.rhs) {
+			rv = a.rhs[r0 + tid];
+			if (a.rscale)
+				rv *= a.rscale[r0 + tid];
+		}
+		if (DSRC == D_DBLOCKS)
+			d = a.dvals[r0 + tid];
+	}
+
+	double v[SWEEP1S_MAX_ROW];
+	int col[SWEEP1S_MAX_ROW];
+#pragma unroll
+	for (int i = 0; i < SWEEP1S_MAX_ROW; i++) {
+		const int q = tid + 256 * i;
+		v[i] = q < nent ? a.vals[(long)jlo + q] : 0.0;
+		col[i] = q < nent ? a.pat.bcolind[jlo + q] : -1;
+	}
+	double xv[SWEEP1S_MAX_ROW];
+#pragma unroll
+	for (int i = 0; i < SWEEP1S_MAX_ROW; i++)
+		xv[i] = col[i] >= 0 ? a.xin[col[i]] : 0.0;
+#pragma unroll
+	for (int i = 0; i < SWEEP1S_MAX_ROW; i++) {
+		const int q = tid + 256 * i;
+		if (q < nent)
+			s_prod[q] = v[i] * xv[i];
+	}
+	__syncthreads();
+
+	if (!ok)
+		return;
+	double acc = 0.0;
+	for (int jj = jbeg; jj < jend; jj++)
+		if (!(PART == PART_OFFDIAG && jj == dg))
+			acc += s_prod[jj - jlo];
+	double out;
+	if (POST == POST_D_SUB)
+		out = d * (rv - acc);
+	else {
+		out = a.a * acc;
+		if (a.b != 0.0)
+			out += a.b * rv;
+	}
+	a.xout[r0 + tid] = out;
+}
+
 // tuning "scalarlane=auto|0|1|2|3|4": 0 = the general kernel everywhere, 1 / 2 = this kernel with one / two rows per
 // lane, 3 = as 1 and for the whole-row operators too, 4 = the one-wave sequential form; auto (-1, default) = this
 // kernel (one row per lane) for sweeps that write a SECOND buffer -- synchronous / deterministic sweeps, where only
@@ -168,6 +252,8 @@ int g_scalar_lane = [] {
 	const char *e = std::getenv("BLASTED_HIP_SCALARLANE");
 	return e ? std::atoi(e) : -1;
 }();
+
+int g_scalar_stage = 1;
 
 template <int NR, bool SEQ>
 bool dispatch1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
@@ -197,6 +283,11 @@ void set_scalar_lane(int v)
 	g_scalar_lane = v;
 }
 
+void set_scalar_stage(int v)
+{
+	g_scalar_stage = v;
+}
+
 bool launch_sweep1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
 	if (a.pat.bs != 1 || g_scalar_lane == 0 || a.pat.max_row_len > SWEEP1_MAX_ROW)
@@ -205,8 +296,20 @@ bool launch_sweep1(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStrea
 	// loads a wave each spread over 28 cache lines -- measured SLOWER than the general kernel from 200^3 on (256^3:
 	// product 0.50 against 0.38 ms, relaxation step 1.05 against 0.86 ms; 128^3 equal), so these keep the general
 	// kernel unless asked for ("scalarlane=3")
-	if ((part == PART_ALL || part == PART_OFFDIAG) && g_scalar_lane != 3)
-		return false;
+	if ((part == PART_ALL || part == PART_OFFDIAG) && g_scalar_lane != 3) {
+		// the staged form: product always, relaxation passes into a second buffer ("scalarstage=0": never)
+		if (!g_scalar_stage || a.pat.max_row_len > SWEEP1S_MAX_ROW || (part == PART_OFFDIAG && a.xin == a.xout))
+			return false;
+		const unsigned grid = (unsigned)(((long)a.pat.nbrows + 255) / 256);
+		if (part == PART_ALL && post == POST_AXPBY && dsrc == D_NONE)
+			hipLaunchKernelGGL((sweep1s_kernel<PART_ALL, POST_AXPBY, D_NONE>), dim3(grid), dim3(256), 0, s, a);
+		else if (part == PART_OFFDIAG && post == POST_D_SUB && dsrc == D_DBLOCKS)
+			hipLaunchKernelGGL((sweep1s_kernel<PART_OFFDIAG, POST_D_SUB, D_DBLOCKS>), dim3(grid), dim3(256), 0, s, a);
+		else
+			return false;
+		BHIP_CHECK(hipGetLastError());
+		return true;
+	}
 	if (g_scalar_lane < 0 && a.xin == a.xout && part != PART_NONE)
 		return false;
 	const bool done = g_scalar_lane == 2 ? dispatch1<2, false>(a, part, post, dsrc, s)

@@ -54,6 +54,7 @@ def main():
         tune["latestore"] = int(rng.choice([0, 1, 2, 2, 4]))     # a workgroup's results stored once, steps in flight
         tune["invertrow"] = int(rng.integers(0, 2))              # eight-lanes-per-block inversion (bs 5..8)
         tune["scalarlane"] = str(rng.choice(["auto", "0", "1", "2", "3", "4"]))       # scalar row sweeps: lanes per row / rows per lane
+        tune["scalarstage"] = int(rng.integers(0, 2))            # whole-row scalar operators: products staged through LDS
         tune["factor1plan"] = int(rng.integers(0, 2))            # scalar in-place factorisation on the precomputed plan
         for k, v in tune.items():
             capi.set_tuning("%s=%s" % (k, v))
@@ -149,7 +150,7 @@ def main():
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
                  "factor8=1", "gunroll=0", "copies=one", "xcdsuper=auto", "levelserial=4096", "levelfast=1",
-                 "factorsf=1", "factorsf=p1", "factorskip=1", "latestore=2", "invertrow=1", "scalarlane=auto", "factor1plan=1",
+                 "factorsf=1", "factorsf=p1", "factorskip=1", "latestore=2", "invertrow=1", "scalarlane=auto", "scalarstage=1", "factor1plan=1",
                  "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))

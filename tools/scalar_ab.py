@@ -50,8 +50,8 @@ def main():
         p.ilu0_factorize(30)
         exact = p.ilu0_apply(r, 1, mode=capi.LEVEL).clone()
         p.jacobi_compute()
-        for lanes, unr in ((0, 0), (1, 0), (4, 0)):
-            capi.set_tuning("scalarlane=%d" % lanes)
+        for lanes, unr in ((0, 0), ("auto", 0), (3, 0)):
+            capi.set_tuning("scalarlane=%s" % lanes)
             capi.set_tuning("gunroll=%d" % unr)
             if unr:
                 print("(general kernel with 2 / 4 row steps in flight: gunroll=2)")
@@ -61,7 +61,7 @@ def main():
                 per = (t12 - t2) / 10
                 z3 = p.ilu0_apply(r, 3, mode=mode, out=z)
                 dist = float((z3 - exact).norm() / exact.norm())
-                print("n=%d scalarlane=%d %-5s ILU apply, one L+U sweep pair %.4f ms  %.2f TB/s = %.3f of peak; 3+3 sweeps: distance to the exact solve %.4f" % (
+                print("n=%d scalarlane=%s %-5s ILU apply, one L+U sweep pair %.4f ms  %.2f TB/s = %.3f of peak; 3+3 sweeps: distance to the exact solve %.4f" % (
                     n, lanes, name, per * 1e3, ab["ilu_pair"] / per / 1e12, ab["ilu_pair"] / per / PEAK, dist), flush=True)
             t1 = timed(lambda: p.sgs_apply(r, 1, mode=capi.JACOBI_SYNC, out=z), 10)
             t11 = timed(lambda: p.sgs_apply(r, 11, mode=capi.JACOBI_SYNC, out=z), 10)
@@ -69,10 +69,10 @@ def main():
             x0 = torch.zeros_like(r)
             tr1 = timed(lambda: p.sgs_relax(r, x0, 1, mode=capi.JACOBI_SYNC), 10)
             tr6 = timed(lambda: p.sgs_relax(r, x0, 6, mode=capi.JACOBI_SYNC), 10)
-            print("n=%d scalarlane=%d SGS relaxation (sync), one forward+backward step %.4f ms = %.3f of peak" % (
+            print("n=%d scalarlane=%s SGS relaxation (sync), one forward+backward step %.4f ms = %.3f of peak" % (
                 n, lanes, (tr6 - tr1) / 5 * 1e3, 2 * ab["sgs_relax_pass"] / ((tr6 - tr1) / 5) / PEAK), flush=True)
             ts = timed(lambda: p.spmv(r, out=z), 20)
-            print("n=%d scalarlane=%d SGS sync sweep pair %.4f ms = %.3f of peak; SpMV %.4f ms = %.3f of peak" % (
+            print("n=%d scalarlane=%s SGS sync sweep pair %.4f ms = %.3f of peak; SpMV %.4f ms = %.3f of peak" % (
                 n, lanes, per * 1e3, ab["sgs_pair"] / per / PEAK, ts * 1e3, ab["spmv"] / ts / PEAK), flush=True)
         capi.set_tuning("scalarlane=auto")
         capi.set_tuning("gunroll=0")
