@@ -517,7 +517,9 @@ def main():
                 except Exception:
                     traffic, traffic_source = None, None
             family = ("sweepw_kernel<%d, ...>" % bs if bs in (4, 8) else
-                      "sweepodd_kernel<%d, ...>" % bs if bs in (3, 5, 7) else "sweep_kernel<%d, ...>" % bs)
+                      "sweepodd_kernel<%d, ...>" % bs if bs in (3, 5, 7) else
+                      # scalar rows: the product takes the LDS-staged form; in-place sweeps the general kernel
+                      "sweep1s_kernel<...>" if (bs == 1 and op == "spmv") else "sweep_kernel<%d, ...>" % bs)
             # a 64^3 scalar problem is 22 MB: it lives in the L2s / the 256 MB Infinity Cache and a sweep is an
             # 8 us launch -- the step is bound by launch latency and cache bandwidth, not by HBM
             cache_resident = ab["ilu_pair"] < 128e6

@@ -20,7 +20,8 @@ def one(pattern):
 
 # bench config number -> (key in profiles/traffic.json = the workload name, name fragments of its dominant kernel)
 CONFIG_KERNELS = {
-    "1": ("poisson3d_64_csr_async_ilu0_apply", ("sweep1_kernel<1, 1, 3,", "sweep_kernel<1, false, 1,")),
+    # (in-place scalar sweeps: the general kernel, "scalarlane=auto")
+    "1": ("poisson3d_64_csr_async_ilu0_apply", ("sweep_kernel<1, false, 1,", "sweep1_kernel<1, 1, 3,")),
     # (bench.py also times the interleaved row order beside the default: the IW instantiation, last template argument true)
     # (default in-place sweep: natural order, late store, two row steps in flight = UNR 2, LS true)
     "2": ("ilu_apply", ("sweepw_kernel<4, 1, 1, 1, 128, true, 2, 1, false, false, false, true>", "sweepw_kernel<4, 1,", "sweep_kernel<")),
@@ -85,7 +86,8 @@ def main(tag, op="ilu_apply"):
             "sgs_relax": ("sweepw_kernel<4, 2,", "sweep_kernel<"), "spmv": ("sweepw_kernel<4, 3,", "sweep_kernel<"),
             "factor": ("factor4_kernel", "factor_sweep_kernel"),
             # ad-hoc scalar profiles at 256^3 (bench.py --n 256 --bs 1 --op factor | ilu_apply)
-            "scalar_factor": ("factor1p_kernel", "factor1_kernel"), "scalar_sweeps": ("sweep1_kernel<1, 1, 3,", "sweep_kernel<1, false, 1,")}.get(op, ("sweepw_kernel",))
+            "scalar_factor": ("factor1p_kernel", "factor1_kernel"), "scalar_sweeps": ("sweep1_kernel<1, 1, 3,", "sweep_kernel<1, false, 1,"),
+            "scalar_spmv": ("sweep1s_kernel<3, 3, 0>", "sweep_kernel<1, false, 3,")}.get(op, ("sweepw_kernel",))
     if op in CONFIG_KERNELS:  # "summarize_prof.py <tag> <config number>"
         op, want = CONFIG_KERNELS[op]
     dom = []
