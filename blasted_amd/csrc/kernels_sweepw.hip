@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	// sweeps' iteration count, and two steps in flight with a late store is also the fastest form.
 	// bs = 8 (two 16-byte pieces per lane, one row step in flight), 100^3: 0.691 against 0.719 ms per sweep pair, two
 	// applications differ by 5.7e-3 instead of 1.9e-2, GCR(30) 313 iterations instead of 363-365 at 3 sweeps.
+	// (The late store for the in-place RELAXATION passes at bs = 4 -- whole rows, PART_OFFDIAG -- was built and measured at
+	// the end of round 3: 85 / 140 registers with one / two steps in flight, config 3's pass 2.61-2.67 ms in every
+	// form on the same box, i.e. no difference; not kept.)
 	static_assert(!LS || (((BS == 4 && (UNR == 1 || UNR == 2 || UNR == 4)) || (BS == 8 && UNR == 1)) && NBV == 1 && !SC && !IW &&
 	                      (PART == PART_LOWER || PART == PART_UPPER)), "late store");
 	static_assert(!IW || (BS == 4 && UNR == 1 && NBV == 1 && !SC && (PART == PART_LOWER || PART == PART_UPPER)),
