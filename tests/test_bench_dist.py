@@ -82,3 +82,27 @@ def test_algorithmic_bytes_match_survey():
     # the bytes an in-place sweep touches once the pair-less upper blocks are left alone: 3 arrays x their blocks less
     ab6 = bench.algorithmic_bytes(6, 4)
     assert ab6["factor_sweep"] - ab6["factor_sweep_touched"] == 3 * nnzu * 128
+
+
+def test_live_traffic_picks_the_dominant_kernel_from_a_counter_csv(tmp_path):
+    """bench.py's roofline.traffic comes from rocprofv3 --pmc passes it starts itself: the parser must pick the kernel
+    the roofline is quoted on (the descending sweep for the apply ops, by its PART template argument and family) and
+    average its launches -- checked here on a counter CSV of the shape rocprofv3 writes."""
+    import bench
+    rows = [("void bhip::sweepw_kernel<4, 0, 0, 0, 128, true, 2, 1, false, false, false, true>(bhip::SweepArgs)", 4000000.0)] * 9
+    rows += [("void bhip::sweepw_kernel<4, 1, 1, 1, 128, true, 2, 1, false, false, false, true>(bhip::SweepArgs)", 5000000.0)] * 8
+    rows += [("void bhip::sweepw_kernel<4, 1, 1, 1, 128, true, 2, 1, false, false, false, true>(bhip::SweepArgs)", 5200000.0)]
+    rows += [("void bhip::(anonymous namespace)::sfw_kernel<4, true, 1, true, 2, false>(bhip::SweepArgs, int const*)", 9e6)] * 2
+    rows += [("bhip::(anonymous namespace)::factor4_kernel(bhip::FactorArgs)", 17000000.0)] * 3
+    rows += [("void at::native::vectorized_elementwise_kernel<4, foo>", 1.0)] * 40
+    rows += [("void bhip::sweep_kernel<1, false, 1, 1, 3, 1, false>(bhip::SweepArgs)", 10000.0)] * 2
+    f = tmp_path / "1_counter_collection.csv"
+    with open(f, "w") as fh:
+        fh.write("Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n")
+        for i, (k, v) in enumerate(rows):
+            fh.write('%d,%d,0,1,1,1,256,7,"%s",256,0,0,64,0,32,FETCH_SIZE,%r,0,1\n' % (i, i, k, v))
+    name, avg, n = bench.dominant_kernel_counter(str(f), "ilu_apply")
+    assert "sweepw_kernel<4, 1, 1, 1" in name and n == 9 and abs(avg - (8 * 5e6 + 5.2e6) / 9) < 1e-6
+    name, avg, n = bench.dominant_kernel_counter(str(f), "factor")
+    assert "factor4_kernel" in name and n == 3 and avg == 17000000.0
+    assert bench.dominant_kernel_counter(str(f), "spmv") is None

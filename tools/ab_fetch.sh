@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 for t in "$@"; do
   tag=$(echo "$t" | tr -c 'a-zA-Z0-9\n' '_')
   if [ "$t" = "default" ]; then unset BLASTED_HIP_TUNING; else export BLASTED_HIP_TUNING="$t"; fi
-  timeout -k 10 300 python3 /root/repo/bench.py --no-cpu-baseline $ARGS > $O/bench_$tag.json 2> $O/bench_$tag.err || { echo "bench failed for $t"; tail -3 $O/bench_$tag.err; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O/tcc_$tag -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARGS > /dev/null 2> $O/tcc_$tag.err || echo "tcc pass failed"
+  timeout -k 10 300 python3 /root/repo/bench.py --no-cpu-baseline --live-traffic off $ARGS > $O/bench_$tag.json 2> $O/bench_$tag.err || { echo "bench failed for $t"; tail -3 $O/bench_$tag.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O/tcc_$tag -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --live-traffic off $ARGS > /dev/null 2> $O/tcc_$tag.err || echo "tcc pass failed"
   python3 - <<PY
 import json, csv, glob, collections
 d=json.loads(open("$O/bench_$tag.json").read().strip().splitlines()[-1])

@@ -9,7 +9,7 @@ timeout -k 10 400 python tools/ab_config.py --config 4 --rounds 4 "sweepodd=nt0;
 cat $O/ab_timing.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_RDREQ[A-Za-z0-9_]*\|TCC_EA0_WRREQ[A-Za-z0-9_]*\|TCC_BUBBLE[A-Za-z0-9_]*\|TCC_READ[A-Za-z0-9_]*\|TCP_TCC[A-Za-z0-9_]*" | sort -u > $O/counter_names.txt
-B="python3 /root/repo/bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline"
+B="python3 /root/repo/bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --live-traffic off"
 for v in default nt1 probe; do
   case $v in default) export BLASTED_HIP_TUNING="";; nt1) export BLASTED_HIP_TUNING="sweepodd=nt1";; probe) export BLASTED_HIP_TUNING="gatherprobe=1";; esac
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${v}_fetch -- $B > /dev/null 2> $O/${v}_fetch.err || echo "$v fetch failed"

@@ -5,7 +5,7 @@ O=/root/repo/gpurun_out/r03_lds
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_]*LDS[A-Z_0-9]*\|SQ_INSTS_[A-Z_0-9]*\|SQ_INST_CYCLES[A-Z_0-9]*\|SQ_ACTIVE_INST_[A-Z_0-9]*" | sort -u > $O/counter_names.txt
-B="python3 /root/repo/bench.py --config 4 --op factor --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
+B="python3 /root/repo/bench.py --config 4 --op factor --steps 2 --warmup 1 --no-cpu-baseline --live-traffic off --no-other-configs"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/lds -- $B > /dev/null 2> $O/lds.err || echo "lds pass failed"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $O/inst -- $B > /dev/null 2> $O/inst.err || echo "inst pass failed"
 python3 - <<'PY'
