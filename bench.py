@@ -426,9 +426,18 @@ def live_traffic(argv, op, budget_s=330.0):
             return None, "time budget spent before the %s pass" % counter
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         try:
-            subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + cmd_tail, cwd="/tmp",
-                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=min(left, 200.0),
-                           check=True)
+            # (own session: on a timeout the whole group goes, not only the profiler's launcher)
+            proc = subprocess.Popen([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + cmd_tail, cwd="/tmp",
+                                    env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=min(left, 200.0))
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, "%s pass timed out" % counter
+            if rc != 0:
+                return None, "%s pass exited with %d" % (counter, rc)
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if not files:
                 return None, "%s pass wrote no counter file" % counter
