@@ -501,7 +501,7 @@ def main():
                 "spmv": "spmv", "factor": "async_ilu0_factor"}[op]
         cfg["workload"] = "%s_%d_bs%d_%s" % ("unstructured" if cfg["gen"] == "unstructured" else "poisson3d", n, bs, kind)
 
-    live, live_note = None, "not asked for"
+    live, live_note, live_others = None, "not asked for", {}
     under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY"))
     if under_profiler:
         live_note = "this process runs under a profiler itself"
@@ -509,6 +509,15 @@ def main():
             and os.environ.get("BLASTED_BENCH_PMC_CHILD") != "1" and (args.live_traffic == "on" or not under_profiler)):
         # (before anything here touches the GPU: the passes are child processes with the device to themselves)
         live, live_note = live_traffic(sys.argv[1:], op)
+        if live is not None and args.config == 2 and not custom and not args.no_other_configs:
+            # the short runs of the other configurations get their dominant kernel's traffic the same way
+            t_live = time.perf_counter()
+            for k in (3, 4, 5, 1):
+                if time.perf_counter() - t_live > 150.0:
+                    break
+                lk, _ = live_traffic(["--config", str(k)], CONFIGS[k]["op"], budget_s=90.0)
+                if lk is not None:
+                    live_others[k] = lk
 
     import torch
     import torch.distributed as dist
@@ -790,6 +799,13 @@ def main():
                     torch.cuda.empty_cache()
             except Exception as e:
                 others.append({"failed": repr(e)})
+            for o in others:
+                lk = live_others.get(o.get("baseline_config")) if isinstance(o, dict) else None
+                if lk is not None and "roofline" in o:
+                    o["roofline"]["traffic"] = lk["hbm_bytes_per_launch"]
+                    o["roofline"]["traffic_over_algorithmic"] = lk["hbm_bytes_per_launch"] / o["roofline"]["algorithmic_bytes_per_launch"]
+                    o["roofline"]["traffic_source"] = {"live": True, "kernel": lk["kernel"], "launches_per_pass": lk["launches_per_pass"],
+                                                       "seconds": round(lk["seconds"], 1)}
             out["other_configs"] = others
         if not dry and world == 1 and not args.no_cpu_baseline:
             try:
