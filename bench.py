@@ -501,7 +501,7 @@ def main():
                 "spmv": "spmv", "factor": "async_ilu0_factor"}[op]
         cfg["workload"] = "%s_%d_bs%d_%s" % ("unstructured" if cfg["gen"] == "unstructured" else "poisson3d", n, bs, kind)
 
-    live, live_note, live_others = None, "not asked for", {}
+    live, live_note, live_others, live_factor = None, "not asked for", {}, None
     under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY"))
     if under_profiler:
         live_note = "this process runs under a profiler itself"
@@ -509,6 +509,9 @@ def main():
             and os.environ.get("BLASTED_BENCH_PMC_CHILD") != "1" and (args.live_traffic == "on" or not under_profiler)):
         # (before anything here touches the GPU: the passes are child processes with the device to themselves)
         live, live_note = live_traffic(sys.argv[1:], op)
+        if live is not None and op == "ilu_apply":
+            # the factorisation sweep timed beside the apply: the same two passes of this configuration with --op factor
+            live_factor, _ = live_traffic([a for a in sys.argv[1:]] + ["--op", "factor"], "factor", budget_s=90.0)
         if live is not None and args.config == 2 and not custom and not args.no_other_configs:
             # the short runs of the other configurations get their dominant kernel's traffic the same way
             t_live = time.perf_counter()
@@ -716,12 +719,17 @@ def main():
                 fms = tf_["lower_ms"] / max(tf_["lower_launches"], 1)
                 tb = ab["factor_sweep_touched"]
                 ftraffic = None
+                if live_factor is not None:
+                    ftraffic = {"hbm_bytes_per_launch": live_factor["hbm_bytes_per_launch"], "live": True,
+                                "kernel": live_factor["kernel"], "launches_per_pass": live_factor["launches_per_pass"],
+                                "seconds": round(live_factor["seconds"], 1)}
                 try:
-                    fent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("factor", {}) if args.config == 2 and not custom else {}
-                    ftraffic = {"hbm_bytes_per_launch": fent.get("hbm_bytes_per_launch"), "profiles": fent.get("from"),
-                                "commit": fent.get("commit")} if fent else None
+                    fent = {} if ftraffic else json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("factor", {}) if args.config == 2 and not custom else {}
+                    if fent:
+                        ftraffic = {"hbm_bytes_per_launch": fent.get("hbm_bytes_per_launch"), "live": False,
+                                    "profiles": fent.get("from"), "commit": fent.get("commit")}
                 except Exception:
-                    ftraffic = None
+                    pass
                 out["factor"] = {"async_factor_ms": asf, "nbuildsweeps": cfg["build"], "sweep_ms": fms, "traffic": ftraffic,
                                  "algorithmic_bytes_per_sweep": ab["factor_sweep"],
                                  "touched_bytes_per_sweep": tb, "fixed_upper_blocks": ab["fixed_upper"],
