@@ -516,6 +516,9 @@ static int g_relax_split = 1;
 // tuning ("factorskip=0|1"): in-place factorisation sweeps after the first leave upper blocks without position
 // pairs alone (their value, the scaled matrix block, does not change from sweep to sweep)
 static int g_factor_skip_fixed = 1;
+// tuning ("factorfuse=1" default / "0"): the initialisation pass of asynchronous INIT_F_ORIGINAL builds (bs >= 2) fused
+// into the first sweep (see blasted_hip_ilu0_factorize)
+static int g_factor_fuse_init = 1;
 // tuning ("factor1plan=0|1"): scalar in-place factorisation sweeps on the precomputed plan (kernels_factor1.hip,
 // factor1p_kernel; default) or with the round-2 kernel
 static int g_factor1_plan = 1;
@@ -879,7 +882,19 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		// entries of its own row and rows of earlier levels only), so its result does not depend on the initial
 		// guess: the 15 GB initialisation pass (4.4 ms of 29.6 at 256^3 bs=4) is skipped unless the initial
 		// remainder is asked for.
-		const bool needs_init = !(nbuildsweeps < 0 && !precinfo);
+		// Asynchronous sweeps from INIT_F_ORIGINAL, no scaling (round 3): the initialisation pass -- a copy of the matrix
+		// into the factor, 4.4 ms of a 28.5 ms three-sweep build at 256^3 bs=4 -- is fused into the first sweep, which reads
+		// its iterate from the MATRIX (in = A, out = factor: every read sees the initial guess F0 = A, a valid schedule of
+		// the chaotic iteration, and every entry is written, the pair-less upper blocks with their final value a_ij); the
+		// sweeps after it run in place as before (same convergence per sweep as with the separate pass, measured on
+		// Poisson and unstructured patterns at bs 3, 4, 5, 8: profiles/r03_factor_fuse_ab.txt).  The row being computed reads its OWN finished lower blocks back from
+		// the factor, as an in-place sweep does (FactorArgs::lrow_fresh): without that the diagonal block of the first
+		// sweep is built from the raw a_ik instead of l_ik and the build falls two sweeps behind (measured).  Not for the scalar kernel, whose in-place form is the fast
+		// one (0.95 against 1.77 ms per sweep at 256^3, more than the pass costs), nor when the initial remainder is asked
+		// for (it is evaluated on the initialised factor).
+		const bool fuse_init = g_factor_fuse_init && fact_init == BLASTED_HIP_INIT_F_ORIGINAL && !use_scaling &&
+		                       mode == BLASTED_HIP_ASYNC && nbuildsweeps >= 1 && !precinfo && pat.bs >= 2;
+		const bool needs_init = !(nbuildsweeps < 0 && !precinfo) && !fuse_init;
 		if (needs_init) {
 			double *dscratch = nullptr;
 			if (fact_init == BLASTED_HIP_INIT_F_SGS)
@@ -963,10 +978,17 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 				fa.out = out;
 				// (from the first sweep on after INIT_F_ORIGINAL: the initialisation pass has stored exactly those values)
 				fa.skip_fixed = ((s > 0 || fact_init == BLASTED_HIP_INIT_F_ORIGINAL) && out == cur && g_factor_skip_fixed) ? 1 : 0;
+				fa.lrow_fresh = 0;
+				if (fuse_init && s == 0) {
+					fa.in = p->vals;  // the initial guess itself; every entry of the factor is written
+					fa.skip_fixed = 0;
+					fa.lrow_fresh = 1;  // ... and a row's own lower blocks are read back fresh, as in place
+				}
 				launch_factor_sweep(fa, p->stream);
 				ph.launches++;
 				cur = out;
 			}
+			fa.lrow_fresh = 0;
 			ph.done();
 		}
 		if (cur != p->iluvals)
@@ -1803,6 +1825,8 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
 			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
+		else if (spec && std::strncmp(spec, "factorfuse=", 11) == 0)
+			g_factor_fuse_init = spec[11] - '0';
 		else if (spec && std::strncmp(spec, "factorprobe=", 12) == 0)
 			set_factor_probe(spec[12] - '0');
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)

@@ -135,6 +135,9 @@ struct FactorArgs {
 	                        // final, and lower blocks multiply with the stored inverse (general kernel only)
 	int skip_fixed;         // in-place sweeps after the first: an upper block without position pairs is the (scaled)
 	                        // matrix block, which the sweep before has stored -- neither read nor written again
+	int lrow_fresh = 0;     // sweeps with in != out: a pair's l_ik, a lower block of the row being computed, is read from
+	                        // `out` (what this sweep has just stored) instead of `in` -- the first sweep of a build whose
+	                        // initialisation pass is fused into it (capi.hip: fuse_init)
 	const int *f1_dcol = nullptr;    // scalar in-place sweeps (kernels_factor1.hip, factor1p_kernel): per entry, the
 	const int4 *f1_chunks = nullptr; // position of its column's diagonal entry (-1: not lower); per chunk, its ranges
 };

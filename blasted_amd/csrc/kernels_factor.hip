@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void factor_sweep_kernel(const FactorArgs a, d
 		}
 		const int kbeg = a.posptr[jpos], kend = a.posptr[jpos + 1];
 		for (int k = kbeg; k < kend; k++) {
-			const double lv = active ? a.in[(long)a.lowerp[k] * BS2 + e] : 0.0;
+			const double lv = active ? (a.lrow_fresh ? a.out : a.in)[(long)a.lowerp[k] * BS2 + e] : 0.0;
 			const double uv = active ? a.in[(long)a.upperp[k] * BS2 + e] : 0.0;
 			if (BS == 1)
 				s -= lv * uv;

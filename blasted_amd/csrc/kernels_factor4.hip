@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 						lp = a.lowerp[kb + kk];
 						up = a.upperp[kb + kk];
 					}
-					lval = a.in[(long)lp * 16 + offA];
+					lval = (a.lrow_fresh ? a.out : a.in)[(long)lp * 16 + offA];
 					uval = a.in[(long)up * 16 + offD];
 				}
 				// upper/diag: sum += L U ; lower: sum^T += U^T L^T (same loads, roles swapped)

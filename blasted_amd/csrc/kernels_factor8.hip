@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 					lp = a.lowerp[kk];
 					up = a.upperp[kk];
 				}
-				const double *const lblk = a.in + (long)lp * 64, *const ublk = a.in + (long)up * 64;
+				const double *const lblk = (a.lrow_fresh ? a.out : a.in) + (long)lp * 64, *const ublk = a.in + (long)up * 64;
 				const double l0 = lblk[offA0], l1 = lblk[offA1];
 				const double u0 = ublk[offB0], u1 = ublk[offB1];
 				acc = mfma444(l0, u0, acc);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 8) void factorodd_kernel(const FactorArgs a, c
 				lv = s;
 				uv = s;
 			} else if (actB) {
-				lv = *reinterpret_cast<const fd2u_t *>(a.in + (long)a.lowerp[k] * BS2 + boff);
+				lv = *reinterpret_cast<const fd2u_t *>((a.lrow_fresh ? a.out : a.in) + (long)a.lowerp[k] * BS2 + boff);
 				uv = *reinterpret_cast<const fd2u_t *>(a.in + (long)a.upperp[k] * BS2 + boff);
 			}
 			double pA, pB;
