@@ -67,6 +67,9 @@ def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed=0):
         # after INIT_F_ORIGINAL, tuning factorskip=1): their matrix block is not read, their factor block neither
         # read nor written; every index array is still walked
         "factor_sweep_touched": 3 * (nnzb - nfixed) * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
+        # the FIRST sweep of an asynchronous build at bs >= 2 (round 3: the initialisation pass is fused into it): the
+        # matrix is both right-hand side and iterate (read once), every factor block is written
+        "factor_sweep_fused_first": 2 * nnzb * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
         "spmv": nnzb * (B + I) + (nb + 1) * I + 2 * nb * S,
         "nbrows": nb, "nnzb": nnzb, "nnzl": nnzl, "nnzu": nnzu, "pairs": npairs, "fixed_upper": nfixed,
     }
@@ -592,6 +595,8 @@ def main():
         step_bytes = ab["sgs_fwd"] + s * ab["sgs_bwd"]
     if op == "factor":
         kbytes = ab["factor_sweep_touched"]
+        if bs >= 2 and s >= 1:  # a build = one fused first sweep + in-place sweeps (see pattern_bytes)
+            kbytes = (ab["factor_sweep_fused_first"] + (s - 1) * ab["factor_sweep_touched"]) / s
 
     for _ in range(args.warmup):
         step()
@@ -718,6 +723,9 @@ def main():
                 p.set_timing(False)
                 fms = tf_["lower_ms"] / max(tf_["lower_launches"], 1)
                 tb = ab["factor_sweep_touched"]
+                if bs >= 2 and cfg["build"] >= 1:
+                    # (the timed sweeps are the build's: one fused first sweep + in-place sweeps; average per sweep)
+                    tb = (ab["factor_sweep_fused_first"] + (cfg["build"] - 1) * ab["factor_sweep_touched"]) / cfg["build"]
                 ftraffic = None
                 if live_factor is not None:
                     ftraffic = {"hbm_bytes_per_launch": live_factor["hbm_bytes_per_launch"], "live": True,
@@ -738,8 +746,10 @@ def main():
                                  "moved_gbps": (ftraffic["hbm_bytes_per_launch"] / (fms * 1e-3) / 1e9
                                                 if ftraffic and ftraffic.get("hbm_bytes_per_launch") and fms > 0 else None),
                                  "note": "in-place sweeps leave upper blocks without position pairs alone (their value "
-                                         "is the matrix block): achieved / frac count the bytes the sweep touches, not "
-                                         "the every-array-once figure"}
+                                         "is the matrix block): achieved / frac count the bytes the sweeps touch, not "
+                                         "the every-array-once figure; at bs >= 2 the build's first sweep reads the matrix "
+                                         "as its iterate and writes every block (the initialisation pass is fused into "
+                                         "it), sweep_ms / touched bytes / traffic are averages over the build's sweeps"}
                 ex = _t(lambda: p.ilu0_apply(r, 1, mode=capi.LEVEL, out=z))
                 st = p.level_stats()
                 sy = _t(lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.JACOBI_SYNC, out=z))
