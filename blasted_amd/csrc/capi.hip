@@ -290,6 +290,31 @@ static int g_level_store = [] {
 // of a chunk also covers the other triangle: +2.4 % HBM traffic at 256^3 bs=4, +7 % time on the
 // unstructured bs=5 case).  Cost: a second copy of the factor and one copy pass per factorisation
 // (6.1 ms at 256^3, repaid after about 20 three-sweep applies).  Results are bit-identical.
+// The copy pass costs what about 20 three-sweep applications gain from it, and a caller that refactorises every few
+// applications (a Newton or time-stepping loop) would pay it every time for nothing: the copies are made when the
+// g_compact_after-th sweep application since the factor (the matrix, for SGS) last changed comes along -- at the
+// break-even point, so whatever the caller does costs at most twice the better of "never" and "at once".  Until then
+// the sweeps read the factor in place (bit-identical results).  tuning "compactafter=N" / BLASTED_HIP_COMPACT_AFTER
+// (0 = with the first application, as rounds 1-2 did and as bench.py asks for: it measures the steady state).
+// Default (-1): by block size, from the measured break-even points (tools/compact_lazy_ab.py,
+// profiles/r03_compact_lazy_ab.txt: a three-sweep build followed by K applications of 3+3 sweeps) -- 16 at bs = 4
+// (256^3: copies at once 40.1 / 187.3 ms at K = 1 / 16 against 34.0 / 189.8 without), 8 at the other block sizes
+// (unstructured bs = 5: even at K ~ 11), 4 for scalar rows (even at K ~ 5: in place a triangular sweep fetches whole
+// rows' lines for half their entries).
+static long g_compact_after = [] {
+	const char *e = std::getenv("BLASTED_HIP_COMPACT_AFTER");
+	return e ? std::atol(e) : -1L;
+}();
+
+// true: this application uses the compact copies (they exist already, or it is time to make them)
+static bool compact_now(const blasted_hip_prec p, long &applies, const blasted_hip_prec_s::TriCopy &c)
+{
+	const long after = g_compact_after >= 0 ? g_compact_after : (p->pat.bs == 4 ? 16 : (p->pat.bs == 1 ? 4 : 8));
+	const bool yes = applies >= after || (c.valid_l && c.valid_u);
+	applies++;
+	return yes;
+}
+
 static int g_compact = [] {
 	const char *e = std::getenv("BLASTED_HIP_COMPACT");
 	return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
@@ -790,6 +815,7 @@ int blasted_hip_set_values(blasted_hip_prec p, const double *vals, int loc)
 		}
 		p->mat_nat.invalidate();
 		p->mat_lvl.invalidate();
+		p->mat_applies = 0;
 	});
 }
 
@@ -850,6 +876,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		(void)deterministic;
 		p->fac_lvl.invalidate();
 		p->fac_nat.invalidate();
+		p->fac_applies = 0;
 		p->fdiag_valid = false;
 		if (mode == BLASTED_HIP_LEVEL)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_factorize: mode LEVEL applies to the apply / relaxation entry "
@@ -1067,7 +1094,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rhs = dr;
 		a.rscale = p->scaled ? p->scale : nullptr;
 		a.descending = 0;
-		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0;
+		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->fac_applies, p->fac_nat);
 		if (compact)
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
@@ -1181,6 +1208,7 @@ int blasted_hip_jacobi_compute(blasted_hip_prec p)
 		p->jacobi_done = true;
 		p->mat_nat.invalidate();  // compute(): the borrowed values may have changed in place
 		p->mat_lvl.invalidate();
+		p->mat_applies = 0;
 		if (!p->ytemp) {  // AsyncBlockSGS::compute, src/solverops_sgs.cpp:33-45
 			p->ytemp = dev_alloc<double>((size_t)p->n());
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, sizeof(double) * (size_t)p->n(), p->stream));
@@ -1271,7 +1299,7 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 			a.dvals = p->dblocks;
 			a.rhs = p->ytemp;
 			a.descending = 1;
-			if (g_compact)
+			if (g_compact && compact_now(p, p->mat_applies, p->mat_nat))
 				compact_args(p, true, a, p->vals, p->mat_nat);
 			const double *first_in = nullptr;
 			int nbwd = napplysweeps;
@@ -1322,7 +1350,7 @@ int blasted_hip_sgs_apply(blasted_hip_prec p, const double *r, double *z, int na
 		a.dvals = p->dblocks;
 		a.rhs = dr;
 		a.descending = 0;
-		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0;
+		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->mat_applies, p->mat_nat);
 		if (skip_fwd)
 			run_sweeps(p, a, PART_NONE, POST_D_SUB, D_DBLOCKS, p->ytemp, nullptr, dr, 1, BLASTED_HIP_ASYNC, 0);
 		if (compact)
@@ -1803,6 +1831,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_interleave = spec[11] == '0' ? 0 : (spec[11] == '2' ? 2 : (spec[11] == '3' ? 3 : 1));  // 2: the round-1 form (through memory); 3: that form for relaxation passes too
 		else if (spec && std::strncmp(spec, "compact=", 8) == 0)
 			g_compact = spec[8] != '0';
+		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
+			g_compact_after = std::atol(spec + 13);
 		else if (spec && std::strncmp(spec, "sfonestep=", 10) == 0)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)

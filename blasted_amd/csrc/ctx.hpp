@@ -290,6 +290,8 @@ struct blasted_hip_prec_s {
 		bool valid_l = false, valid_u = false;
 		void invalidate() { valid_l = valid_u = false; }
 	};
+	long fac_applies = 0, mat_applies = 0;      // sweep applications since the factor / the matrix values last changed
+	                                            // (the compact triangle copies are made once they pay: capi.hip, g_compact_after)
 	double *yperm = nullptr, *zperm = nullptr;  // level-ordered iterates of the exact ILU solves
 	bool y_in_level_order = false;              // yperm holds L^-1 r of the last exact apply, ytemp is stale
 	bool y_natural_too = false;                 // the next exact lower solve also writes y by row (into its x)

@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # barriers dominate.  A modest team keeps the checker fast; bench.py's cpu_baseline is not affected.
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The product makes its compact triangle copies when the 16th sweep application since a factorisation comes along
+# (capi.hip, g_compact_after); the tests apply an operator a few times each and are meant to cover the kernels ON the
+# copies: here the copies are made with the first application (test_gpu_parity.py::test_compact_copies_are_made_lazily
+# covers the policy itself).  Set before the library is loaded, inherited by the native drivers.
+os.environ.setdefault("BLASTED_HIP_COMPACT_AFTER", "0")
 
 
 def pytest_configure(config):

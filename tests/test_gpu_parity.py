@@ -611,6 +611,37 @@ def test_fused_initialisation_builds_the_same_factor(golden, case):
         assert dist["1", sweeps] < 4 * dist["0", sweeps] + 1e-13, (sweeps, dist)
 
 
+def test_compact_copies_are_made_lazily(golden):
+    """The compact triangle copies the asynchronous sweeps read are made when the (compactafter+1)-th sweep application
+    since the last factorisation comes along, not before: a caller that refactorises every few applications never
+    pays the copy pass.  Before and after, synchronous sweeps give the same bits; a new factorisation starts the
+    count again and invalidates the copies."""
+    m = matrices(golden)["poisson16_bs4"]()
+    r = W.rhs_vector(m["nbrows"] * 4)
+    p = make_prec(m)
+    capi.set_tuning("compactafter=3")
+    try:
+        p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)  # (synchronous: the same factor both times)
+        seen = []
+        for k in range(5):
+            seen.append((p.memory_stats()["derived_copies"], p.ilu0_apply(r, 2, mode=capi.JACOBI_SYNC)))
+        seen.append((p.memory_stats()["derived_copies"], None))
+        assert [c for c, _ in seen] == [0, 0, 0, 0, 2, 2]
+        for _, z in seen[1:5]:
+            assert np.array_equal(z, seen[0][1])
+        p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)  # (synchronous: the same factor both times)
+        z = p.ilu0_apply(r, 2, mode=capi.JACOBI_SYNC)
+        assert np.array_equal(z, seen[0][1])
+        p.jacobi_compute()
+        c0 = p.memory_stats()["derived_copies"]
+        for k in range(4):
+            p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC)
+        assert p.memory_stats()["derived_copies"] >= c0
+    finally:
+        capi.set_tuning("compactafter=0")
+        p.close()
+
+
 def test_warm_start_init_none(golden):
     m = matrices(golden)["poisson16_csr"]()
     p = make_prec(m)

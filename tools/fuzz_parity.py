@@ -49,6 +49,7 @@ def main():
         tune["levelserial"] = int(rng.choice([4096, 4096, 8]))   # 8: the in-order fall-back of the level build
         tune["levelfast"] = int(rng.choice([1, 1, 0]))           # the polling launch of the level build
         tune["factorsf"] = str(rng.choice(["0", "1", "1", "2", "3", "p0", "p1"]))  # forms of the exact factorisation
+        tune["compactafter"] = int(rng.choice([0, 0, 1, 3]))      # compact triangle copies made with the (N+1)-th application
         tune["factorfuse"] = int(rng.integers(0, 2))             # initialisation pass fused into the first in-place sweep
         tune["factorskip"] = int(rng.integers(0, 2))             # fixed upper blocks left alone by in-place sweeps
         tune["interleave"] = int(rng.choice([0, 0, 1, 2]))       # row order of the in-place triangular sweeps
@@ -151,7 +152,7 @@ def main():
     for spec in ("level=syncfree", "levelstore=1", "levelwide=1", "levelperm=1", "compact=1", "interleave=0",
                  "sweepodd=1", "sweepodd=nt0", "sweepodd=occ1", "sweepwr=1", "factorodd=1", "factor1=1", "factor4=1",
                  "factor8=1", "gunroll=0", "copies=one", "xcdsuper=auto", "levelserial=4096", "levelfast=1",
-                 "factorsf=1", "factorsf=p1", "factorskip=1", "factorfuse=1", "latestore=2", "invertrow=1", "scalarlane=auto", "scalarstage=1", "factor1plan=1",
+                 "factorsf=1", "factorsf=p1", "factorskip=1", "compactafter=0", "factorfuse=1", "latestore=2", "invertrow=1", "scalarlane=auto", "scalarstage=1", "factor1plan=1",
                  "r128,nt1,u1,s1"):
         capi.set_tuning(spec)
     print("%d cases in %.1f s; worst relative differences:" % (ncases, time.time() - t0))
