@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 	// sweeps' iteration count, and two steps in flight with a late store is also the fastest form.
 	// bs = 8 (two 16-byte pieces per lane, one row step in flight), 100^3: 0.691 against 0.719 ms per sweep pair, two
 	// applications differ by 5.7e-3 instead of 1.9e-2, GCR(30) 313 iterations instead of 363-365 at 3 sweeps.
+	// (The late store for LONG rows -- the LR instantiation, unstructured matrices -- was built and measured too: GCR(30)
+	// on an unstructured Laplacian (x) 4x4 block, 1.33 M rows, 33-34 iterations without / 35 with at 3 sweeps, 67-68 / 77
+	// at 1 sweep, the upper sweep 0.458 / 0.467 ms: no gain, not kept; profiles/r03_solve_compare_unstructured.txt.)
 	// (The late store for the in-place RELAXATION passes at bs = 4 -- whole rows, PART_OFFDIAG -- was built and measured at
 	// the end of round 3: 85 / 140 registers with one / two steps in flight, config 3's pass 2.61-2.67 ms in every
 	// form on the same box, i.e. no difference; not kept.)

@@ -3,7 +3,7 @@
 GCR (tests/solvers.cpp:247-352; device vectors, torch for the vector algebra, this library for SpMV and the
 preconditioner) on the block-inflated 3-D Poisson matrix (Poisson (x) one fixed block) -- iterations and time to
 a relative residual of 1e-8.
-usage: solve_compare.py [n=160] [bs=4] [solver=bcgs|gcr|both] [restart=30] [only=substring ...] [tuning strings ...]
+usage: solve_compare.py [n=160] [bs=4] [solver=bcgs|gcr|both] [restart=30] [gen=poisson|unstructured] [only=substring ...] [tuning strings ...]
 (with tuning strings, e.g. interleave=1, only the asynchronous variants are run)"""
 import sys
 import time
@@ -88,13 +88,22 @@ def main():
     only = [a[5:] for a in sys.argv[3:] if a.startswith("only=")]
     solver = ([a[7:] for a in sys.argv[3:] if a.startswith("solver=")] or ["bcgs"])[-1]
     restart = int(([a[8:] for a in sys.argv[3:] if a.startswith("restart=")] or ["30"])[-1])
-    specs = [a for a in sys.argv[3:] if not a.startswith(("only=", "solver=", "restart="))]
+    gen = ([a[4:] for a in sys.argv[3:] if a.startswith("gen=")] or ["poisson"])[-1]
+    specs = [a for a in sys.argv[3:] if not a.startswith(("only=", "solver=", "restart=", "gen="))]
     dev = torch.device("cuda", 0)
     # Kronecker product (scalar 7-point Poisson) x (one fixed, slightly non-symmetric bs x bs block with
     # positive spectrum): a well-posed system.  (The slot-dependent inflation of workloads.poisson3d, made to
     # exercise every block entry, gives a strongly indefinite operator -- fine for the fixed-point parity
     # tests, useless for a Krylov comparison.)
     ms = W.poisson3d_device(n, 1, dev, grid="uniform")
+    if gen == "unstructured":
+        # the pattern of bench config 4's generator (n^3 rows, ~14 neighbours a row, window-shuffled numbering) with
+        # the values of a shifted graph Laplacian: -1 off the diagonal, degree x 1.02 on it
+        ms = dict(W.unstructured_bsr(n, 1, device=dev))
+        rp = ms["browptr"].long()
+        v = -torch.ones(int(ms["nnzb"]), dtype=torch.float64, device=dev)
+        v[ms["diagind"].long()] = 1.02 * (rp[1:] - rp[:-1] - 1).double()
+        ms["vals"] = v
     r_, c_ = torch.meshgrid(torch.arange(bs, device=dev), torch.arange(bs, device=dev), indexing="ij")
     Mb = torch.eye(bs, dtype=torch.float64, device=dev) * (1.0 + 0.1 * r_) + 0.03 * (((r_ + 2 * c_) % 3) - 1) * (r_ != c_)
     vals = (ms["vals"][:, None] * Mb.t().reshape(-1)[None, :]).reshape(-1)   # column-major blocks
@@ -104,7 +113,7 @@ def main():
     p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
     p.set_matrix(m)
     A = lambda v: p.spmv(v)
-    print("3-D Poisson %d^3, bs=%d, %d block-rows; solver %s to 1e-8" % (n, bs, m["nbrows"], solver))
+    print("%s %d^3, bs=%d, %d block-rows; solver %s to 1e-8" % ("3-D Poisson" if gen == "poisson" else "unstructured Laplacian", n, bs, m["nbrows"], solver))
     variants = [
         ("none", None, lambda v: v),
         ("jacobi", lambda: p.jacobi_compute(), lambda v: p.jacobi_apply(v)),
