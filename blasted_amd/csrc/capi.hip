@@ -916,11 +916,12 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		// sweeps after it run in place as before (same convergence per sweep as with the separate pass, measured on
 		// Poisson and unstructured patterns at bs 3, 4, 5, 8: profiles/r03_factor_fuse_ab.txt).  The row being computed reads its OWN finished lower blocks back from
 		// the factor, as an in-place sweep does (FactorArgs::lrow_fresh): without that the diagonal block of the first
-		// sweep is built from the raw a_ik instead of l_ik and the build falls two sweeps behind (measured).  Not for the scalar kernel, whose in-place form is the fast
-		// one (0.95 against 1.77 ms per sweep at 256^3, more than the pass costs), nor when the initial remainder is asked
-		// for (it is evaluated on the initialised factor).
+		// sweep is built from the raw a_ik instead of l_ik and the build falls two sweeps behind (measured).  Scalar matrices take part through the plan kernel
+		// (kernels_factor1.hip), which reads none of the chunk's old factor values anyway; not when the initial remainder is
+		// asked for (it is evaluated on the initialised factor).
 		const bool fuse_init = g_factor_fuse_init && fact_init == BLASTED_HIP_INIT_F_ORIGINAL && !use_scaling &&
-		                       mode == BLASTED_HIP_ASYNC && nbuildsweeps >= 1 && !precinfo && pat.bs >= 2;
+		                       mode == BLASTED_HIP_ASYNC && nbuildsweeps >= 1 && !precinfo &&
+		                       (pat.bs >= 2 || g_factor1_plan);  // (scalar: on the plan kernel, which reads no old factor value)
 		const bool needs_init = !(nbuildsweeps < 0 && !precinfo) && !fuse_init;
 		if (needs_init) {
 			double *dscratch = nullptr;
@@ -943,7 +944,7 @@ int blasted_hip_ilu0_factorize(blasted_hip_prec p, int nbuildsweeps, int fact_in
 		fa.diag_inverted = 0;
 		fa.skip_fixed = 0;
 		fa.dinv_scratch = nullptr;
-		if (pat.bs == 1 && nbuildsweeps > 0 && mode != BLASTED_HIP_JACOBI_SYNC && !scale && g_factor1_plan) {
+		if (pat.bs == 1 && nbuildsweeps > 0 && mode != BLASTED_HIP_JACOBI_SYNC && !scale && g_factor1_plan) {  // (before the sweeps below)
 			// once per pattern: what the scalar in-place sweep kernel reads instead of column indices
 			if (!p->f1_dcol) {
 				p->f1_dcol = dev_alloc<int>((size_t)pat.nnzb);

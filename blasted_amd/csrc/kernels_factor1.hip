@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void factor1_kernel(const FactorArgs a)
 //    parallel (the same operation on the same operands as in the serial phase: same bits);
 //  * LDS holds 16-bit chunk-relative positions: 28.5 KB per workgroup, five workgroups per CU;
 //  * the serial phase only visits entries that have pairs (a 7-point row: its diagonal entry).
-// Synchronous sweeps (separate buffers) and scaled factorisations keep factor1_kernel.
+// Synchronous sweeps (separate buffers) and scaled factorisations keep factor1_kernel.  The kernel never reads the chunk's
+// own old factor values (a row reads what it has produced) and takes everything else from `in`, so it also runs the
+// fused first sweep of a build, in = the matrix, out = the factor (FactorArgs::lrow_fresh).
 constexpr int F1P_CAPE = 1024, F1P_CAPP = 1024;
 static_assert(F1P_CAPE == F1_CAPE && F1P_CAPP == F1_CAPP, "the chunk descriptors are built for these capacities");
 
@@ -308,6 +310,9 @@ __global__ __launch_bounds__(256) void factor1p_kernel(const FactorArgs a)
 	__syncthreads();
 
 	// ---- one lane per row: the entries with pairs, in storage order (the reference's in-row order)
+	// (a lower entry of the row itself that is not staged is read back from what this sweep has stored: `out`, which is
+	// `in` for an in-place sweep and the factor for the fused first sweep of a build, whose `in` is the matrix)
+	const double *const lsrc = a.out;
 	if (tid < rc) {
 		for (int jpos = rbeg; jpos < rend; jpos++) {
 			const int le = jpos - jlo;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void factor1p_kernel(const FactorArgs a)
 					double s = s_f[le];
 					for (int k = kb; k < ke; k++) {
 						const unsigned short rel = s_lp[k];
-						const double lv = rel != FAR ? s_f[rel] : a.in[a.lowerp[plo + k]];
+						const double lv = rel != FAR ? s_f[rel] : lsrc[a.lowerp[plo + k]];
 						s -= lv * s_uv[k];
 					}
 					if (jpos < rdg)
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void factor1p_kernel(const FactorArgs a)
 			for (int k = kb; k < ke; k++) {
 				const int lp = a.lowerp[k];
 				const int ll = lp - jlo;
-				const double lv = (ll >= 0 && ll < nent) ? s_f[ll] : a.in[lp];
+				const double lv = (ll >= 0 && ll < nent) ? s_f[ll] : lsrc[lp];
 				s -= lv * a.in[a.upperp[k]];
 			}
 			if (jpos < rdg)
@@ -593,7 +598,7 @@ bool launch_factor1(const FactorArgs &a, hipStream_t s)
 	if (!g_factor1_enabled || a.pat.bs != 1 || a.pat.nbrows == 0 || a.rows || !a.out)
 		return false;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F1_RCHUNK - 1) / F1_RCHUNK);
-	if (a.in == a.out && !a.scale && a.f1_dcol && a.f1_chunks)
+	if ((a.in == a.out || a.lrow_fresh) && !a.scale && a.f1_dcol && a.f1_chunks)
 		hipLaunchKernelGGL(factor1p_kernel, dim3(grid), dim3(256), 0, s, a);
 	else if (a.in == a.out)
 		hipLaunchKernelGGL(factor1_kernel<true>, dim3(grid), dim3(256), 0, s, a);

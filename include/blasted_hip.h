@@ -250,7 +250,7 @@ int blasted_hip_measure_read_stream(const void *dev_ptr, unsigned long nbytes, i
  * whole-row operators too (3), or its one-wave sequential form (4) (environment: BLASTED_HIP_SCALARLANE);
  * "compactafter=N" (default -1 = by block size: 16 / 8 / 4 for bs 4 / other / 1): the compact triangle copies the
  * asynchronous sweeps read are made with the (N+1)-th application since the factor (matrix) last changed;
- * "factorfuse=1" (default) / "0": asynchronous builds from INIT_F_ORIGINAL (bs >= 2, no scaling) read the matrix itself
+ * "factorfuse=1" (default) / "0": asynchronous builds from INIT_F_ORIGINAL (no scaling) read the matrix itself
  * in their first sweep instead of a copy made by an initialisation pass;
  * "scalarstage=1" (default) / "0": scalar product and relaxation passes into a second buffer with the products staged
  * through LDS (rows of at most 8 entries), or the general kernel; "factor1plan=1" (default) / "0": scalar in-place factorisation sweeps on the per-pattern plan or with the round-2

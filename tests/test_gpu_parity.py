@@ -577,7 +577,8 @@ def test_odd_block_factor_kernels_agree(shape):
 
 
 @pytest.mark.parametrize("case", ["poisson16_bs4", "2dcyl1_bs4_col", "2dcyl1_bs4_row", "poisson12_bs5", "poisson9_bs8",
-                                  "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4"])
+                                  "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4",
+                                  "poisson16_csr", "random_csr", "2dcyl1_csr", "msc_csr"])
 def test_fused_initialisation_builds_the_same_factor(golden, case):
     """Asynchronous builds from INIT_F_ORIGINAL fuse the initialisation pass into the first sweep (in = the matrix,
     out = the factor, a row's own lower blocks read back fresh): after ONE sweep the pair-less upper blocks hold
