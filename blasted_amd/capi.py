@@ -7,6 +7,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, "lib", "libblasted_hip.so")
+# measurement tools only (tools/probes/): BLASTED_HIP_PROBES=1 loads the -DBHIP_PROBES build of the same sources
+if os.environ.get("BLASTED_HIP_PROBES") == "1":
+    LIBPATH = os.path.join(HERE, "lib", "libblasted_hip_probes.so")
 
 OK, EINVAL, ENODEV, ERUNTIME, ESTATE, ENOTIMPL = 0, 1, 2, 3, 4, 5
 COLMAJOR, ROWMAJOR = 0, 1

@@ -34,6 +34,7 @@ struct AllocRegistry {
 	struct Rec {
 		size_t bytes;
 		blasted_hip_prec owner;
+		void *base;  // what hipMalloc returned (differs from the key under "allocoff")
 	};
 	std::mutex mu;
 	std::map<void *, Rec> recs;
@@ -45,15 +46,25 @@ AllocRegistry &alloc_registry()
 }
 }  // namespace
 
+// Placement studies (tuning "allocoff=BYTES" / BLASTED_HIP_ALLOC_OFFSET, a multiple of 256): every device allocation
+// of 64 MiB and more starts BYTES into a correspondingly larger hipMalloc block.  Results cannot change.
+static size_t g_alloc_offset = [] {
+	const char *e = std::getenv("BLASTED_HIP_ALLOC_OFFSET");
+	return e ? (size_t)std::atol(e) & ~(size_t)255 : (size_t)0;
+}();
+
 hipError_t tracked_malloc(void **p, size_t bytes)
 {
-	const hipError_t e = hipMalloc(p, bytes);
+	const size_t off = bytes >= (64u << 20) ? g_alloc_offset : 0;
+	void *base = nullptr;
+	const hipError_t e = hipMalloc(&base, bytes + off);
 	if (e != hipSuccess)
 		return e;
+	*p = static_cast<char *>(base) + off;
 	trace_alloc(*p, bytes);
 	AllocRegistry &r = alloc_registry();
 	std::lock_guard<std::mutex> lk(r.mu);
-	r.recs[*p] = {bytes, tl_owner};
+	r.recs[*p] = {bytes, tl_owner, base};
 	if (tl_owner) {
 		tl_owner->bytes_owned += (long)bytes;
 		if (tl_owner->bytes_owned > tl_owner->bytes_peak)
@@ -71,6 +82,7 @@ hipError_t tracked_free(void *p)
 		if (it != r.recs.end()) {
 			if (it->second.owner)
 				it->second.owner->bytes_owned -= (long)it->second.bytes;
+			p = it->second.base;
 			r.recs.erase(it);
 		}
 	}
@@ -1834,6 +1846,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_compact = spec[8] != '0';
 		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
 			g_compact_after = std::atol(spec + 13);
+		else if (spec && std::strncmp(spec, "allocoff=", 9) == 0)
+			g_alloc_offset = (size_t)std::atol(spec + 9) & ~(size_t)255;
 		else if (spec && std::strncmp(spec, "sfonestep=", 10) == 0)
 			set_syncfree_one_step(spec[10] != '0');
 		else if (spec && std::strncmp(spec, "levelwide=", 10) == 0)
@@ -1904,6 +1918,157 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepw_variant(spec);
 	});
 }
+
+#ifdef BHIP_PROBES
+/* ---- placement probes (libblasted_hip_probes.so only; tools/probes/placement_streams.py) ------------------- */
+// Re-allocates one of the operator's buffers (under the current "allocoff"), contents preserved or rebuilt by the
+// next application: "ytemp", "ucopy" / "lcopy" (natural-order triangle copies of the factor), "nat" (the compact
+// pattern of those copies and both copies), "iluvals".
+int blasted_hip_probe_move(blasted_hip_prec p, const char *what)
+{
+	return guarded([&] {
+		use_device(p);
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+		const std::string w = what ? what : "";
+		auto move = [&](double *&buf, size_t count) {
+			if (!buf)
+				return;
+			double *nb = dev_alloc<double>(count);
+			BHIP_CHECK(hipMemcpy(nb, buf, sizeof(double) * count, hipMemcpyDeviceToDevice));
+			dev_free(buf);
+			buf = nb;
+		};
+		if (w == "ytemp")
+			move(p->ytemp, (size_t)p->n());
+		else if (w == "iluvals") {
+			move(p->iluvals, (size_t)p->nvals());
+			p->fac_nat.invalidate();
+		} else if (w == "ucopy") {
+			dev_free(p->fac_nat.u);
+			p->fac_nat.u = nullptr;
+			p->fac_nat.valid_u = false;
+		} else if (w == "lcopy") {
+			dev_free(p->fac_nat.l);
+			p->fac_nat.l = nullptr;
+			p->fac_nat.valid_l = false;
+		} else if (w == "nat") {
+			for (auto *c : {&p->fac_nat, &p->mat_nat}) {
+				dev_free(c->l);
+				dev_free(c->u);
+				c->l = c->u = nullptr;
+				c->invalidate();
+			}
+			free_level_schedule(p->natstore);
+		} else
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_move: ytemp | iluvals | ucopy | lcopy | nat");
+	});
+}
+
+// Points one of the operator's buffers at caller-owned device memory (an arena slot; 0 = forget it again, nothing is
+// freed).  The operator's own buffer is freed first.  "ucopy" / "lcopy" are re-filled by the next application.
+int blasted_hip_probe_place(blasted_hip_prec p, const char *what, void *where)
+{
+	return guarded([&] {
+		use_device(p);
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+		const std::string w = what ? what : "";
+		double *&buf = w == "ytemp" ? p->ytemp : (w == "ucopy" ? p->fac_nat.u : p->fac_nat.l);
+		if (w != "ytemp" && w != "ucopy" && w != "lcopy")
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_place: ytemp | ucopy | lcopy");
+		{
+			AllocRegistry &r = alloc_registry();
+			bool mine;
+			{
+				std::lock_guard<std::mutex> lk(r.mu);
+				mine = r.recs.count(buf) != 0;
+			}
+			if (mine)
+				dev_free(buf);
+		}
+		buf = static_cast<double *>(where);
+		if (w == "ucopy")
+			p->fac_nat.valid_u = false;
+		if (w == "lcopy")
+			p->fac_nat.valid_l = false;
+		if (w == "ytemp" && where)
+			BHIP_CHECK(hipMemset(where, 0, sizeof(double) * (size_t)p->n()));
+	});
+}
+
+// Device memory built by hand (placement studies): a virtual range of `bytes` whose start is aligned to `va_align`,
+// backed by physical allocations of `chunk` bytes each (the last one smaller), mapped in order.  Never freed.
+int blasted_hip_probe_vmm_alloc(unsigned long bytes, unsigned long va_align, unsigned long chunk, void **out)
+{
+	return guarded([&] {
+		int dev = 0;
+		BHIP_CHECK(hipGetDevice(&dev));
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned;
+		prop.location.type = hipMemLocationTypeDevice;
+		prop.location.id = dev;
+		size_t gran = 0;
+		BHIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+		if (!gran || chunk % gran || bytes % gran)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_vmm_alloc: sizes must be multiples of the allocation granularity");
+		void *va = nullptr;
+		BHIP_CHECK(hipMemAddressReserve(&va, bytes, va_align, nullptr, 0));
+		for (size_t at = 0; at < bytes; at += chunk) {
+			const size_t sz = bytes - at < chunk ? bytes - at : chunk;
+			hipMemGenericAllocationHandle_t h;
+			BHIP_CHECK(hipMemCreate(&h, sz, &prop, 0));
+			BHIP_CHECK(hipMemMap(static_cast<char *>(va) + at, sz, 0, h, 0));
+			BHIP_CHECK(hipMemRelease(h));  // the mapping keeps the memory
+		}
+		hipMemAccessDesc acc = {};
+		acc.location = prop.location;
+		acc.flags = hipMemAccessFlagsProtReadWrite;
+		BHIP_CHECK(hipMemSetAccess(va, bytes, &acc, 1));
+		BHIP_CHECK(hipMemset(va, 0, bytes));
+		*out = va;
+	});
+}
+
+// Addresses of the buffers the asynchronous ILU application streams: out[0..5] = ytemp, lower copy, upper copy,
+// iluvals, lower / upper column indices of the copies (0 where absent).
+int blasted_hip_probe_addresses(blasted_hip_prec p, unsigned long *out6)
+{
+	return guarded([&] {
+		use_device(p);
+		out6[0] = (unsigned long)(uintptr_t)p->ytemp;
+		out6[1] = (unsigned long)(uintptr_t)p->fac_nat.l;
+		out6[2] = (unsigned long)(uintptr_t)p->fac_nat.u;
+		out6[3] = (unsigned long)(uintptr_t)p->iluvals;
+		out6[4] = (unsigned long)(uintptr_t)p->natstore.lcol;
+		out6[5] = (unsigned long)(uintptr_t)p->natstore.ucol;
+	});
+}
+
+// ns per dependent load of a one-lane walk over [ptr, ptr + nbytes) with `stride` bytes between loads, starting
+// `start` bytes in (a multiple of 8 below the stride, so that repeated walks touch fresh cache lines)
+int blasted_hip_probe_page_walk(const void *ptr, unsigned long nbytes, unsigned long stride, unsigned long start, double *ns)
+{
+	return guarded([&] {
+		const long nloads = (long)((nbytes - start) / stride);
+		if (!ptr || nloads < 1 || (stride & 7) || (start & 7))
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_page_walk");
+		double *sink = dev_alloc<double>(1);
+		hipEvent_t e0, e1;
+		BHIP_CHECK(hipEventCreate(&e0));
+		BHIP_CHECK(hipEventCreate(&e1));
+		BHIP_CHECK(hipDeviceSynchronize());
+		BHIP_CHECK(hipEventRecord(e0, nullptr));
+		launch_page_walk(static_cast<const char *>(ptr) + start, nloads, (long)stride, sink, nullptr);
+		BHIP_CHECK(hipEventRecord(e1, nullptr));
+		BHIP_CHECK(hipEventSynchronize(e1));
+		float ms = 0.f;
+		BHIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+		BHIP_CHECK(hipEventDestroy(e0));
+		BHIP_CHECK(hipEventDestroy(e1));
+		dev_free(sink);
+		*ns = (double)ms * 1e6 / (double)nloads;
+	});
+}
+#endif  // BHIP_PROBES
 
 /* ---- timing -------------------------------------------------------------------------------- */
 

@@ -236,6 +236,7 @@ struct Timing {
 	double launches[3] = {0, 0, 0};
 };
 
+void launch_page_walk(const void *buf, long nloads, long stride_bytes, double *sink, hipStream_t s);  // probes build
 void trace_alloc(const void *p, size_t bytes);  // capi.hip
 
 // Device allocations of the library go through these two (capi.hip): same contract as hipMalloc / hipFree,

@@ -261,6 +261,30 @@ __global__ __launch_bounds__(256) void read_stream_kernel(const double *__restri
 		sink[0] = acc;
 }
 
+#ifdef BHIP_PROBES
+// One lane walks the buffer with one dependent 8-byte load per `stride` bytes (probes build: how much of a
+// buffer's address range one translation covers -- a stride of 2 MiB pays a page walk per load where the
+// driver mapped the range in 2 MiB fragments and none where it is one large fragment).
+__global__ void page_walk_kernel(const double *__restrict__ buf, long nloads, long stride8, double *sink)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0)
+		return;
+	long at = 0;
+	double acc = 0;
+	for (long k = 0; k < nloads; k++) {
+		const double v = __builtin_nontemporal_load(buf + at);
+		acc += v;
+		at += stride8 + (v == 1.2345e300 ? 1 : 0);  // the next address depends on the loaded value
+	}
+	sink[0] = acc;
+}
+
+void launch_page_walk(const void *buf, long nloads, long stride_bytes, double *sink, hipStream_t s)
+{
+	hipLaunchKernelGGL(page_walk_kernel, dim3(1), dim3(64), 0, s, static_cast<const double *>(buf), nloads, stride_bytes / 8, sink);
+}
+#endif
+
 void launch_read_stream(const void *buf, unsigned long nbytes, double *sink, hipStream_t s)
 {
 	const long n16 = (long)(nbytes / 16);
