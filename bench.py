@@ -701,6 +701,8 @@ def main():
                 "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
                 "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
                 "other_ms_per_step": tm["other_ms"] / args.steps}
+            out["placement"] = dict(capi.placement_stats(), note="class-aware placement of the triangle copies "
+                                    "(blasted_hip_placement_stats): 2 GiB pieces checked against the vector the sweep writes")
             if cache_resident:
                 out["roofline"]["note"] = ("working set %.0f MB: cache-resident, launch-latency bound (%.1f us per step "
                                            "over %d launches); frac is against the HBM peak only for uniformity" % (

@@ -33,7 +33,7 @@ SYMBOLS = [
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
     "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
     "blasted_hip_device_synchronize", "blasted_hip_memory_stats", "blasted_hip_host_register",
-    "blasted_hip_host_unregister",
+    "blasted_hip_host_unregister", "blasted_hip_placement_stats",
 ]
 
 _lib = None
@@ -143,6 +143,13 @@ def host_register(a):
 
 def host_unregister(a):
     _check(lib().blasted_hip_host_unregister(a.ctypes.data))
+
+
+def placement_stats():
+    """process-wide counters of the class-aware placement (include/blasted_hip.h)"""
+    out = (C.c_long * 5)()
+    _check(lib().blasted_hip_placement_stats(out))
+    return dict(zip(("buffers", "pieces", "turned_down", "unchecked", "probes"), [int(v) for v in out]))
 
 
 def device_count():

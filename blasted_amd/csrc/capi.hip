@@ -4,6 +4,7 @@
 // the kernel translation units; there is no CPU compute path in this library.
 #include "ctx.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -35,6 +36,10 @@ struct AllocRegistry {
 		size_t bytes;
 		blasted_hip_prec owner;
 		void *base;  // what hipMalloc returned (differs from the key under "allocoff")
+		// class-aware allocations (placed_alloc): a reserved address range of va_bytes with physical pieces mapped
+		// into it, each (offset, size)
+		size_t va_bytes = 0;
+		std::vector<std::pair<size_t, size_t>> pieces;
 	};
 	std::mutex mu;
 	std::map<void *, Rec> recs;
@@ -64,7 +69,11 @@ hipError_t tracked_malloc(void **p, size_t bytes)
 	trace_alloc(*p, bytes);
 	AllocRegistry &r = alloc_registry();
 	std::lock_guard<std::mutex> lk(r.mu);
-	r.recs[*p] = {bytes, tl_owner, base};
+	AllocRegistry::Rec rec;
+	rec.bytes = bytes;
+	rec.owner = tl_owner;
+	rec.base = base;
+	r.recs[*p] = rec;
 	if (tl_owner) {
 		tl_owner->bytes_owned += (long)bytes;
 		if (tl_owner->bytes_owned > tl_owner->bytes_peak)
@@ -83,6 +92,20 @@ hipError_t tracked_free(void *p)
 			if (it->second.owner)
 				it->second.owner->bytes_owned -= (long)it->second.bytes;
 			p = it->second.base;
+			if (it->second.va_bytes) {  // a class-aware allocation: unmap its pieces, give the range back
+				// (hipFree waits for the device before it releases memory; hipMemUnmap does not, and a sweep that still
+				// streams this buffer would fault)
+				hipError_t e = hipDeviceSynchronize();
+				for (const auto &pc : it->second.pieces) {
+					const hipError_t e1 = hipMemUnmap(static_cast<char *>(p) + pc.first, pc.second);
+					e = e == hipSuccess ? e1 : e;
+				}
+				// The address range itself is NOT handed back (hipMemAddressFree): a later reservation that got such a
+				// range again and mapped new memory into it took a "Memory access fault" on first touch (ROCm 7.2, round 4,
+				// twice); address space is not a scarce resource.
+				r.recs.erase(it);
+				return e;
+			}
 			r.recs.erase(it);
 		}
 	}
@@ -111,6 +134,289 @@ static void dev_free(void *p)
 {
 	if (p)
 		(void)tracked_free(p);
+}
+
+// ---- class-aware placement of the sweeps' large buffers -----------------------------------------------------------
+// Measured in round 4 (profiles/r04_placement_{streams,slots,pairs,map,rwprobe,interleave}.txt): the 288 GiB of an
+// MI355X fall into three address classes of 96 GiB (presumably the three ranks of the 12-high HBM3E stacks; which class
+// a piece of memory is in follows from its PHYSICAL address, which the driver chooses).  A kernel that streams one
+// buffer and writes another takes 10-12 % longer when both lie in the same class (256^3 bs=4 upper sweep 1.82 against
+// 1.63-1.66 ms, lower 1.45 against 1.37 ms), and a read stream that alternates between classes is 5 % slower than one
+// that stays in one.  This is the whole of the "fast / slow mode" that rounds 1-3 saw move from process to process and
+// from allocation to allocation: whether a 2 GiB piece of a triangle copy happened to share its class with the vector
+// the sweep writes.  So the copies a sweep STREAMS are built piece by piece (hipMemCreate / hipMemMap, 2 GiB pieces)
+// and every piece is CHECKED -- the address-class probe of kernels_aux.hip, timed with its writes inside the piece
+// (same class by construction) and with its writes in the reference vector -- before it is kept: `avoid` = the vector
+// the sweep writes (a piece of the same class is handed back and another one asked for), `same` = a vector the copy
+// should share its class with.  Pieces that are turned down stay allocated until the search is over, so that the driver
+// cannot offer them again.  tuning "placement=0" / BLASTED_HIP_PLACEMENT=0: plain hipMalloc as before.
+static int g_placement = [] {
+	const char *e = std::getenv("BLASTED_HIP_PLACEMENT");
+	return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
+}();
+
+struct PlaceStats {
+	long placed_buffers = 0, pieces = 0, rejected = 0, gave_up = 0, probes = 0;
+};
+static PlaceStats g_place_stats;
+
+// ms of one launch of the address-class probe: the fastest of `reps` launches after one warm-up; a piece smaller than
+// 4 GiB is read several times per launch, so that every launch moves about 4 GiB (0.8 ms)
+static double probe_ms(const void *rd, size_t rd_bytes, void *wr, size_t wr_bytes, int reps, double *sink, hipStream_t s)
+{
+	const long passes = (long)((((size_t)4 << 30) + rd_bytes - 1) / rd_bytes);
+	std::vector<hipEvent_t> ev((size_t)reps + 1);
+	for (auto &e : ev)
+		BHIP_CHECK(hipEventCreate(&e));
+	launch_rw_probe(rd, (long)rd_bytes, wr, (long)wr_bytes, sink, s, passes);
+	BHIP_CHECK(hipEventRecord(ev[0], s));
+	for (int r = 0; r < reps; r++) {
+		launch_rw_probe(rd, (long)rd_bytes, wr, (long)wr_bytes, sink, s, passes);
+		BHIP_CHECK(hipEventRecord(ev[(size_t)r + 1], s));
+	}
+	BHIP_CHECK(hipEventSynchronize(ev[(size_t)reps]));
+	double best = 1e300;
+	for (int r = 0; r < reps; r++) {
+		float ms = 0.f;
+		BHIP_CHECK(hipEventElapsedTime(&ms, ev[(size_t)r], ev[(size_t)r + 1]));
+		best = ms < best ? ms : best;
+	}
+	for (auto &e : ev)
+		BHIP_CHECK(hipEventDestroy(e));
+	g_place_stats.probes++;
+	return best;
+}
+
+struct PlaceHint {
+	const void *avoid = nullptr, *avoid2 = nullptr, *same = nullptr;
+	size_t ref_bytes = 0;  // length of those vectors
+	bool any() const { return avoid || avoid2 || same; }
+};
+
+// Does `piece` (device memory; its contents are rewritten unchanged) satisfy the hint?  +1 yes, -1 no, 0 cannot tell.
+// The probe is timed once with its writes inside the piece itself (the "same class" time) and once per reference vector.
+static int class_fits(void *piece, size_t piece_bytes, const PlaceHint &h, double *sink, hipStream_t s)
+{
+	size_t rd = piece_bytes < ((size_t)2 << 30) ? piece_bytes : ((size_t)2 << 30);
+	rd &= ~(size_t)0xffff;
+	size_t wr = (rd >> 4) & ~(size_t)0xfff;
+	if (wr > h.ref_bytes)
+		wr = h.ref_bytes & ~(size_t)0xfff;
+	if (rd < ((size_t)32 << 20) || wr < 4096)
+		return 0;
+	const int reps = 3;
+	// same class: ratio 0.99-1.01; another class: about 0.90
+	const double thr = 0.955;
+	static const bool trace = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
+	const double t_self = probe_ms(piece, rd, static_cast<char *>(piece) + rd - wr, wr, reps, sink, s);
+	int fits = +1;
+	const void *refs[3] = {h.same, h.avoid, h.avoid2};
+	for (int k = 0; k < 3 && fits > 0; k++) {
+		if (!refs[k])
+			continue;
+		const double t_ref = probe_ms(piece, rd, const_cast<void *>(refs[k]), wr, reps, sink, s);
+		const bool other_class = t_ref < thr * t_self;
+		if (trace)
+			std::fprintf(stderr, "[blasted_hip] class probe: piece %p (%zu MiB) against %p: self %.4f ms, ref %.4f ms, ratio %.3f -> %s (wanted: %s)\n",
+			             piece, piece_bytes >> 20, refs[k], t_self, t_ref, t_ref / t_self, other_class ? "another class" : "same class",
+			             k == 0 ? "same" : "another");
+		if (other_class != (k != 0))
+			fits = -1;
+	}
+	return fits;
+}
+
+// How much device memory a search may hold back while it looks for pieces of the right class (they are released when
+// the buffer is complete).  Consecutive allocations usually come from one class until the driver's free blocks of that
+// class run out, so a search can need tens of GiB -- and the driver's allocation calls take anything from 0.1 ms to
+// seconds each (freed memory is wiped asynchronously): the default is a QUICK search (16 GiB: helps when the driver's
+// free lists are mixed, gives up otherwise and keeps what it got); tuning "placement=2" / BLASTED_HIP_PLACEMENT=2 is the
+// THOROUGH one (up to 200 GiB held back for a moment: the fast mode every time, for long solves on one rank per GPU).
+static size_t place_budget(size_t bytes)
+{
+	size_t want = g_placement >= 2 ? (size_t)200 << 30 : (size_t)16 << 30;
+	// never more than what is free now, less the buffer itself and a reserve for everybody else on the device
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+		return 0;
+	const size_t reserve = bytes + total_b / 8;
+	const size_t room = free_b > reserve ? free_b - reserve : 0;
+	return want < room ? want : room;
+}
+
+static bool trace_placement()
+{
+	static const bool on = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
+	return on;
+}
+
+static double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// device memory of `bytes` whose pieces satisfy the hint (see above); nullptr: not applicable / not available (the
+// caller allocates plainly)
+static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
+{
+	const void *ref = h.same ? h.same : (h.avoid ? h.avoid : h.avoid2);
+	if (!g_placement || !ref || bytes < ((size_t)256 << 20) || h.ref_bytes < ((size_t)16 << 20))
+		return nullptr;
+	static const bool trace = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
+	const double t_start = now_ms();
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return nullptr;
+	hipMemAllocationProp prop = {};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = dev;
+	size_t gran = 0;
+	if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
+		return nullptr;
+	// EQUAL pieces of 1 GiB (one piece of the buffer's size if that is no more): inside one reserved range ROCm 7.2's
+	// hipMemSetAccess turns down pieces of unequal sizes at some offsets (tools/probes/vmm_rules.hip: 768 MiB behind
+	// 1 GiB, 512 MiB behind 3 GiB -- "invalid argument"), equal ones never
+	const size_t piece = (size_t)1 << 30;
+	const size_t unit = bytes <= piece ? ((size_t)2 << 20) : piece;
+	if (unit % gran)
+		return nullptr;
+	const size_t total = (bytes + unit - 1) / unit * unit;
+	void *va = nullptr;
+	if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess)
+		return nullptr;
+	hipMemAccessDesc acc = {};
+	acc.location = prop.location;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	std::vector<std::pair<size_t, size_t>> mapped;
+	std::vector<hipMemGenericAllocationHandle_t> held;  // turned-down pieces and spacers: allocated until the search is over
+	size_t held_bytes = 0;
+	const size_t budget = place_budget(total);
+	// Every candidate piece is looked at in an address range of its own (never used again) and only a piece that is kept is
+	// mapped into the buffer: no address is ever mapped twice (see tracked_free for what that is about).
+	const size_t max_tries = total / piece + 2 + budget / piece;
+	char *scratch = nullptr;
+	if (hipMemAddressReserve(reinterpret_cast<void **>(&scratch), max_tries * piece, 0, nullptr, 0) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;  // (the buffer's own range is kept reserved: address space is not scarce)
+	}
+	size_t tries = 0;
+	double *sink = nullptr;
+	bool ok = hipMalloc(&sink, sizeof(double)) == hipSuccess;
+	int misses = 0;           // consecutive pieces of the wrong class
+	long unchecked = 0, turned = 0;
+	for (size_t at = 0; ok && at < total;) {
+		const size_t sz = total - at < piece ? total - at : piece;
+		// after two misses in a row: step over a larger stretch of the driver's free memory without looking at it
+		if (misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget) {
+			size_t sp = (size_t)1 << (30 + (misses < 6 ? misses - 1 : 5));  // 2, 4, 8, 16, 32 GiB
+			while (held_bytes + sp > budget && sp > piece)
+				sp >>= 1;
+			hipMemGenericAllocationHandle_t hs;
+			if (hipMemCreate(&hs, sp, &prop, 0) == hipSuccess) {
+				held.push_back(hs);
+				held_bytes += sp;
+			} else
+				(void)hipGetLastError();
+		}
+		hipMemGenericAllocationHandle_t hd;
+		hipError_t e = hipMemCreate(&hd, sz, &prop, 0);
+		if (e != hipSuccess) {
+			if (trace)
+				std::fprintf(stderr, "[blasted_hip] placed_alloc: hipMemCreate(%zu) failed: %s\n", sz, hipGetErrorString(e));
+			(void)hipGetLastError();
+			ok = false;
+			break;
+		}
+		char *where = static_cast<char *>(va) + at;
+		const bool may_reject = held_bytes + sz <= budget && tries < max_tries;
+		int rel = 0;
+		if (may_reject) {
+			char *look = scratch + (tries++) * piece;
+			e = hipMemMap(look, sz, 0, hd, 0);
+			if (e == hipSuccess)
+				e = hipMemSetAccess(look, sz, &acc, 1);
+			if (e == hipSuccess) {
+				try {
+					rel = class_fits(look, sz, h, sink, s);
+				} catch (...) {
+					if (trace)
+						std::fprintf(stderr, "[blasted_hip] placed_alloc: probe failed: %s\n", g_last_error.c_str());
+					rel = 0;
+				}
+				(void)hipStreamSynchronize(s);
+				(void)hipMemUnmap(look, sz);
+			} else
+				(void)hipGetLastError();
+		}
+		if (rel < 0) {
+			held.push_back(hd);
+			held_bytes += sz;
+			misses++;
+			turned++;
+			g_place_stats.rejected++;
+			continue;
+		}
+		e = hipMemMap(where, sz, 0, hd, 0);
+		if (e == hipSuccess)
+			e = hipMemSetAccess(where, sz, &acc, 1);
+		if (e != hipSuccess) {
+			if (trace)
+				std::fprintf(stderr, "[blasted_hip] placed_alloc: mapping %zu bytes at %p failed: %s\n", sz, (void *)where, hipGetErrorString(e));
+			(void)hipMemRelease(hd);
+			ok = false;
+			break;
+		}
+		if (rel == 0) {
+			unchecked++;
+			g_place_stats.gave_up++;
+		}
+		misses = 0;
+		(void)hipMemRelease(hd);  // the mapping keeps the memory
+		mapped.emplace_back(at, sz);
+		g_place_stats.pieces++;
+		at += sz;
+	}
+	for (auto hd : held)
+		(void)hipMemRelease(hd);
+	if (sink)
+		(void)hipFree(sink);
+	if (!ok) {
+		(void)hipDeviceSynchronize();
+		for (const auto &pc : mapped)
+			(void)hipMemUnmap(static_cast<char *>(va) + pc.first, pc.second);
+		(void)hipGetLastError();  // (the address range is kept, see tracked_free)
+		return nullptr;
+	}
+	trace_alloc(va, bytes);
+	if (trace)
+		std::fprintf(stderr, "[blasted_hip] placed %zu MiB at %p (%s %p): %zu pieces, %ld turned down, %ld kept unchecked, %zu MiB "
+		             "held back for the search, %.1f ms\n", total >> 20, va, h.same ? "class of" : "not the class of", ref,
+		             mapped.size(), turned, unchecked, held_bytes >> 20, now_ms() - t_start);
+	AllocRegistry &r = alloc_registry();
+	std::lock_guard<std::mutex> lk(r.mu);
+	AllocRegistry::Rec rec;
+	rec.bytes = total;
+	rec.owner = tl_owner;
+	rec.base = va;
+	rec.va_bytes = total;
+	rec.pieces = std::move(mapped);
+	r.recs[va] = rec;
+	if (tl_owner) {
+		tl_owner->bytes_owned += (long)total;
+		if (tl_owner->bytes_owned > tl_owner->bytes_peak)
+			tl_owner->bytes_peak = tl_owner->bytes_owned;
+	}
+	g_place_stats.placed_buffers++;
+	return va;
+}
+
+template <typename T>
+static T *dev_alloc_placed(size_t count, const PlaceHint &h, hipStream_t s)
+{
+	if (void *p = placed_alloc(sizeof(T) * count, h, s))
+		return static_cast<T *>(p);
+	return dev_alloc<T>(count);
 }
 
 template <typename F>
@@ -353,14 +659,24 @@ static void refresh_copy(blasted_hip_prec p, const LevelSchedule &st, const doub
 	const long bs2 = (long)p->pat.bs * p->pat.bs;
 	double *&mine = upper ? c.u : c.l;
 	bool &valid = upper ? c.valid_u : c.valid_l;
+	if (!mine && !g_keep_both_copies) {
+		// the same triangle in the other ordering has the same size: take its storage over instead of freeing it and
+		// allocating anew (round 4: no allocation when an operator alternates between the two kinds of application, and a
+		// buffer that was placed with care -- placed_alloc -- stays where it is)
+		double *&theirs = upper ? other.u : other.l;
+		mine = theirs;
+		theirs = nullptr;
+		(upper ? other.valid_u : other.valid_l) = false;
+		valid = false;
+	}
 	if (!mine) {
-		if (!g_keep_both_copies) {
-			double *&theirs = upper ? other.u : other.l;
-			dev_free(theirs);
-			theirs = nullptr;
-			(upper ? other.valid_u : other.valid_l) = false;
-		}
-		mine = dev_alloc<double>((size_t)((upper ? st.nnz_dupper : st.nnz_lower) * bs2));
+		PlaceHint hint;
+		hint.avoid = p->place_avoid;
+		hint.same = p->place_same;
+		hint.ref_bytes = p->place_ref_bytes;
+		if (trace_placement())
+			std::fprintf(stderr, "[blasted_hip] %s triangle copy, %s order:\n", upper ? "upper" : "lower", &st == &p->natstore ? "natural" : "level");
+		mine = dev_alloc_placed<double>((size_t)((upper ? st.nnz_dupper : st.nnz_lower) * bs2), hint, p->stream);
 		valid = false;
 	}
 	if (!valid) {
@@ -413,7 +729,102 @@ static bool level_view(blasted_hip_prec p, bool upper, LevelView &v, const doubl
 	return true;
 }
 
+// Address classes of a triangular-sweep application (profiles/r04_placement_combo.txt, 256^3 bs=4): a sweep is fastest
+// when everything it READS lies in one class and the vector it WRITES in another --
+//   lower sweep (streams the lower copy, reads r, writes ytemp): ytemp in the copy's class 1.46 ms; elsewhere 1.31 (r
+//     in the copy's class) / 1.34 (r in the third class) / 1.36 (r in ytemp's class);
+//   upper sweep (streams the upper copy, reads ytemp, writes z): z in the copy's class 1.83 ms; elsewhere 1.62 (ytemp in
+//     the copy's class) / 1.65-1.67 (ytemp elsewhere).
+// So, when the compact copies are made (the caller's r and z are at hand): the lower copy goes into r's class, ytemp is
+// moved out of r's and z's classes if it is in one of them, and the upper copy goes into ytemp's class.  With r and z
+// in one class -- the usual case for a caller's vectors -- that is lower 1.31 / upper 1.62 ms every time.
+static void set_place_hint(blasted_hip_prec p, const void *avoid, const void *same)
+{
+	p->place_avoid = avoid;
+	p->place_same = same;
+	p->place_ref_bytes = (avoid || same) ? sizeof(double) * (size_t)p->n() : 0;
+}
+
+// BLASTED_HIP_TRACE_PLACEMENT: where everything ended up -- every stream of the application against r, z and ytemp
+static void report_classes(blasted_hip_prec p, const double *dr, const double *dz)
+{
+	if (!trace_placement())
+		return;
+	const size_t nbytes = sizeof(double) * (size_t)p->n();
+	double *sink = dev_alloc<double>(1);
+	struct Item {
+		const char *name;
+		void *ptr;
+		size_t bytes;
+	};
+	const LevelSchedule &ns = p->natstore;
+	const size_t lb = (size_t)ns.nnz_lower * p->pat.bs * p->pat.bs * 8, ub = (size_t)ns.nnz_dupper * p->pat.bs * p->pat.bs * 8;
+	std::vector<Item> items = {{"ytemp", p->ytemp, nbytes}, {"r", const_cast<double *>(dr), nbytes}, {"z", const_cast<double *>(dz), nbytes}};
+	for (size_t at = 0; p->fac_nat.l && at + ((size_t)512 << 20) <= lb; at += (size_t)1 << 30)
+		items.push_back({"lower copy piece", reinterpret_cast<char *>(p->fac_nat.l) + at, lb - at < ((size_t)1 << 30) ? lb - at : ((size_t)1 << 30)});
+	for (size_t at = 0; p->fac_nat.u && at + ((size_t)512 << 20) <= ub; at += (size_t)1 << 30)
+		items.push_back({"upper copy piece", reinterpret_cast<char *>(p->fac_nat.u) + at, ub - at < ((size_t)1 << 30) ? ub - at : ((size_t)1 << 30)});
+	if (ns.lcol)
+		items.push_back({"lower column indices", ns.lcol, (size_t)ns.nnz_lower * 4});
+	if (ns.ucol)
+		items.push_back({"upper column indices", ns.ucol, (size_t)ns.nnz_dupper * 4});
+	const void *refs[3] = {dr, dz, p->ytemp};
+	const char *rn[3] = {"r", "z", "ytemp"};
+	for (const Item &it : items) {
+		std::string line;
+		for (int k = 0; k < 3; k++) {
+			if (it.ptr == refs[k]) {
+				line += std::string(" ") + rn[k] + ":itself";
+				continue;
+			}
+			size_t rd = it.bytes & ~(size_t)0xffff, wr = (rd >> 4) & ~(size_t)0xfff;
+			if (rd < ((size_t)32 << 20))
+				continue;
+			const double t_self = probe_ms(it.ptr, rd, static_cast<char *>(it.ptr) + rd - wr, wr, 4, sink, p->stream);
+			const double t_ref = probe_ms(it.ptr, rd, const_cast<void *>(refs[k]), wr, 4, sink, p->stream);
+			char buf[64];
+			std::snprintf(buf, sizeof buf, " %s:%.3f", rn[k], t_ref / t_self);
+			line += buf;
+		}
+		std::fprintf(stderr, "[blasted_hip] classes: %-22s %p (%5zu MiB) time ratio against%s   (about 1: same class, below 0.96: another)\n",
+		             it.name, it.ptr, it.bytes >> 20, line.c_str());
+	}
+	dev_free(sink);
+}
+
+static void place_ytemp(blasted_hip_prec p, const double *dr, const double *dz)
+{
+	const size_t nbytes = sizeof(double) * (size_t)p->n();
+	if (!g_placement || p->ytemp_placed || !p->ytemp || nbytes < ((size_t)256 << 20))
+		return;
+	p->ytemp_placed = true;
+	PlaceHint h;
+	h.avoid = dr;
+	h.avoid2 = dz;
+	h.ref_bytes = nbytes;
+	double *sink = dev_alloc<double>(1);
+	if (trace_placement())
+		std::fprintf(stderr, "[blasted_hip] ytemp against r and z:\n");
+	const int fits = class_fits(p->ytemp, nbytes, h, sink, p->stream);
+	dev_free(sink);
+	if (fits >= 0)
+		return;
+	double *moved = static_cast<double *>(placed_alloc(nbytes, h, p->stream));
+	if (!moved)
+		return;
+	BHIP_CHECK(hipMemcpyAsync(moved, p->ytemp, nbytes, hipMemcpyDeviceToDevice, p->stream));
+	BHIP_CHECK(hipStreamSynchronize(p->stream));
+	dev_free(p->ytemp);
+	p->ytemp = moved;
+}
+
 static int g_level_perm = 1;  // tuning: exact ILU solves keep their iterate level-ordered (bs 4/8 column-major)
+
+// tuning "applynone=1" (tests: the reference's "-initialization exact" fixed-point cases of the triangular sweeps,
+// tests/solverops/async_triangular_factors_convergence.cpp:121-141): blasted_hip_ilu0_apply accepts INIT_A_NONE --
+// the lower sweeps start from the operator's current ytemp, the upper sweeps from the caller's z.  Off by default:
+// the reference's apply throws for that init type (src/solverops_ilu0.cpp:125-126), and so does this one.
+static int g_apply_allow_none = 0;
 
 // ytemp in natural order again (after an exact apply that kept y level-ordered)
 static void restore_ytemp(blasted_hip_prec p)
@@ -1074,7 +1485,9 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		need_pattern(p);
 		if (!p->factored)
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "ilu0_apply before ilu0_factorize");
-		if (apply_init != BLASTED_HIP_INIT_A_ZERO && apply_init != BLASTED_HIP_INIT_A_JACOBI)
+		const bool keep_iterates = g_apply_allow_none && apply_init == BLASTED_HIP_INIT_A_NONE && mode == BLASTED_HIP_ASYNC &&
+		                           loc == BLASTED_HIP_DEVICE && napplysweeps > 0;
+		if (apply_init != BLASTED_HIP_INIT_A_ZERO && apply_init != BLASTED_HIP_INIT_A_JACOBI && !keep_iterates)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, " scalar_ilu0_apply: Invalid init type!");
 		if (!r || !z)
 			BHIP_FAIL(BLASTED_HIP_EINVAL, "ilu0_apply: null vector");
@@ -1086,6 +1499,8 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		double *dz = out_vec(p, z, loc, 1);
 		const bool scalar = p->pat.bs == 1;
 		const bool jac = mode == BLASTED_HIP_JACOBI_SYNC;
+		if (keep_iterates)
+			restore_ytemp(p);  // (an exact apply may have left y level-ordered)
 		p->y_in_level_order = false;  // this call rewrites ytemp
 
 		// Synchronous sweeps start from a known iterate, so their first sweep needs no matrix: from y0 = 0 the
@@ -1096,7 +1511,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 
 		// y := 0 (both init types), src/solverops_ilu0.cpp:83-94.  The prologue z := S r is fused: the
 		// lower sweeps read r (times scale) directly as their right-hand side.
-		if (!skip_first) {
+		if (!skip_first && !keep_iterates) {
 			Phase ph(p, 2);
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
 			ph.launches = 1;
@@ -1108,8 +1523,12 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rscale = p->scaled ? p->scale : nullptr;
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->fac_applies, p->fac_nat);
-		if (compact)
+		if (compact) {
+			set_place_hint(p, nullptr, dr);  // the lower copy in r's class (see place_ytemp) ...
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
+			set_place_hint(p, nullptr, nullptr);
+			place_ytemp(p, dr, dz);          // ... ytemp in neither r's nor z's ...
+		}
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y;
 		if (skip_first) {
@@ -1137,8 +1556,14 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.dvals = p->iluvals;
 		a.rhs = y;
 		a.descending = 1;
-		if (compact)
+		if (compact) {
+			set_place_hint(p, nullptr, p->ytemp);  // ... and the upper copy in ytemp's
+			const bool fresh = !p->fac_nat.u;
 			compact_args(p, true, a, p->iluvals, p->fac_nat);
+			set_place_hint(p, nullptr, nullptr);
+			if (fresh)
+				report_classes(p, dr, dz);
+		}
 		const DSrc dsrc = scalar ? D_RECIP_DIAG : D_VALS_DIAG;
 		double *zfinal = dz;
 		if (napplysweeps == 0) {
@@ -1153,7 +1578,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 			const double *first_in = nullptr;
 			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
 				first_in = y;  // z0 = y: the first sweep gathers from y, no copy needed
-			else {
+			else if (!keep_iterates) {
 				Phase ph(p, 2);
 				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
 				ph.launches = 1;
@@ -1635,6 +2060,19 @@ int blasted_hip_memory_stats(blasted_hip_prec p, long *out4)
 	});
 }
 
+int blasted_hip_placement_stats(long *out5)
+{
+	return guarded([&] {
+		if (!out5)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "placement_stats: null output");
+		out5[0] = g_place_stats.placed_buffers;
+		out5[1] = g_place_stats.pieces;
+		out5[2] = g_place_stats.rejected;
+		out5[3] = g_place_stats.gave_up;
+		out5[4] = g_place_stats.probes;
+	});
+}
+
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr)
 {
 	return guarded([&] {
@@ -1846,6 +2284,10 @@ int blasted_hip_set_tuning(const char *spec)
 			g_compact = spec[8] != '0';
 		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
 			g_compact_after = std::atol(spec + 13);
+		else if (spec && std::strncmp(spec, "placement=", 10) == 0)
+			g_placement = spec[10] == '0' ? 0 : (spec[10] == '2' ? 2 : 1);
+		else if (spec && std::strncmp(spec, "applynone=", 10) == 0)
+			g_apply_allow_none = spec[10] != '0';
 		else if (spec && std::strncmp(spec, "allocoff=", 9) == 0)
 			g_alloc_offset = (size_t)std::atol(spec + 9) & ~(size_t)255;
 		else if (spec && std::strncmp(spec, "sfonestep=", 10) == 0)
@@ -2040,6 +2482,56 @@ int blasted_hip_probe_addresses(blasted_hip_prec p, unsigned long *out6)
 		out6[3] = (unsigned long)(uintptr_t)p->iluvals;
 		out6[4] = (unsigned long)(uintptr_t)p->natstore.lcol;
 		out6[5] = (unsigned long)(uintptr_t)p->natstore.ucol;
+	});
+}
+
+// ms of one launch of the read-beside-write probe (kernels_aux.hip), average of `reps` after two warm-up launches
+int blasted_hip_probe_rw(const void *rd, unsigned long rd_bytes, void *wr, unsigned long wr_bytes, int reps, double *ms_out)
+{
+	return guarded([&] {
+		double *sink = dev_alloc<double>(1);
+		hipEvent_t e0, e1;
+		BHIP_CHECK(hipEventCreate(&e0));
+		BHIP_CHECK(hipEventCreate(&e1));
+		const long passes = reps < 0 ? (long)((((size_t)4 << 30) + rd_bytes - 1) / rd_bytes) : 1;  // reps < 0: the product's form
+		reps = reps < 0 ? -reps : reps;
+		for (int r = 0; r < 2; r++)
+			launch_rw_probe(rd, (long)rd_bytes, wr, (long)wr_bytes, sink, nullptr, passes);
+		BHIP_CHECK(hipEventRecord(e0, nullptr));
+		for (int r = 0; r < reps; r++)
+			launch_rw_probe(rd, (long)rd_bytes, wr, (long)wr_bytes, sink, nullptr, passes);
+		BHIP_CHECK(hipEventRecord(e1, nullptr));
+		BHIP_CHECK(hipEventSynchronize(e1));
+		float ms = 0.f;
+		BHIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+		BHIP_CHECK(hipEventDestroy(e0));
+		BHIP_CHECK(hipEventDestroy(e1));
+		dev_free(sink);
+		*ms_out = (double)ms / reps;
+	});
+}
+
+// GB/s of a read stream of 2 x bytes_each whose pieces alternate between r0 and r1 (kernels_aux.hip)
+int blasted_hip_probe_read2(const void *r0, const void *r1, unsigned long bytes_each, unsigned long piece, int reps, double *gbps)
+{
+	return guarded([&] {
+		double *sink = dev_alloc<double>(1);
+		hipEvent_t e0, e1;
+		BHIP_CHECK(hipEventCreate(&e0));
+		BHIP_CHECK(hipEventCreate(&e1));
+		for (int r = 0; r < 2; r++)
+			launch_read2_probe(r0, r1, (long)bytes_each, (long)piece, sink, nullptr);
+		BHIP_CHECK(hipEventRecord(e0, nullptr));
+		for (int r = 0; r < reps; r++)
+			launch_read2_probe(r0, r1, (long)bytes_each, (long)piece, sink, nullptr);
+		BHIP_CHECK(hipEventRecord(e1, nullptr));
+		BHIP_CHECK(hipEventSynchronize(e1));
+		float ms = 0.f;
+		BHIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+		BHIP_CHECK(hipEventDestroy(e0));
+		BHIP_CHECK(hipEventDestroy(e1));
+		dev_free(sink);
+		*gbps = 2.0 * (double)bytes_each * reps / (ms * 1e-3) / 1e9;
 	});
 }
 

@@ -236,6 +236,8 @@ struct Timing {
 	double launches[3] = {0, 0, 0};
 };
 
+void launch_read2_probe(const void *r0, const void *r1, long bytes_each, long piece_bytes, double *sink, hipStream_t s);  // probes build
+void launch_rw_probe(const void *rd, long rd_bytes, void *wr, long wr_bytes, double *sink, hipStream_t s, long passes = 1);  // kernels_aux.hip: address-class probe
 void launch_page_walk(const void *buf, long nloads, long stride_bytes, double *sink, hipStream_t s);  // probes build
 void trace_alloc(const void *p, size_t bytes);  // capi.hip
 
@@ -302,6 +304,12 @@ struct blasted_hip_prec_s {
 	bhip::Timing timing;
 
 	long bytes_owned = 0, bytes_peak = 0;  // device memory this operator holds (tracked_malloc)
+
+	// class-aware placement (capi.hip, placed_alloc): what the next derived copy should avoid / share its address
+	// class with -- set by the entry point around the call that may allocate the copy
+	const void *place_avoid = nullptr, *place_same = nullptr;
+	size_t place_ref_bytes = 0;
+	bool ytemp_placed = false;  // ytemp has been checked against (and moved out of) the classes of a caller's r and z
 
 	long n() const { return (long)pat.nbrows * pat.bs; }
 	long nvals() const { return (long)pat.nnzb * pat.bs * pat.bs; }

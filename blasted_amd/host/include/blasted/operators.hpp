@@ -61,6 +61,9 @@ int sweep_mode_from_string(const char *m);
 /// "deterministic": synchronous sweeps, a fixed operator (any Krylov method); "exact": level-scheduled solves.
 void set_sweep_mode(const char *m);
 const char *sweep_mode_name();
+/// true when the process-wide mode was chosen by somebody (set_sweep_mode or one of the environment variables)
+/// rather than being the built-in default
+bool sweep_mode_is_explicit();
 
 }  // namespace detail
 
@@ -157,6 +160,11 @@ public:
 	void apply_relax_device(const scalar *const db, scalar *const dx) const { relax_at(db, dx, 1); }
 	/// false for operators that have nothing to run on the device (NoPreconditioner)
 	virtual bool deviceVectorsAvailable() const { return true; }
+	/// How THIS operator applies its asynchronous sweeps (ilu0, sgs): BLASTED_HIP_ASYNC, BLASTED_HIP_DETERMINISTIC or
+	/// BLASTED_HIP_LEVEL; a negative value (the default) follows the process-wide choice (detail::set_sweep_mode,
+	/// BLASTED_HIP_SWEEP_MODE).  Not in the reference; the PCSHELL glue sets it per KSP tree.
+	void setSweepMode(const int mode) { sweepmode_ = mode; }
+	int sweepMode() const { return sweepmode_ >= 0 ? sweepmode_ : detail::HipOperator::sweep_mode(); }
 
 protected:
 	/// the one implementation behind apply / apply_device and apply_relax / apply_relax_device:
@@ -167,6 +175,7 @@ protected:
 	SRMatrixStorage<const scalar, const index> pmat;
 	CRawBSRMatrix<scalar, index> mat;
 	std::unique_ptr<detail::HipOperator> op;
+	int sweepmode_ = -1;
 };
 
 template <typename scalar, typename index>

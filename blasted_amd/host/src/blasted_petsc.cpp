@@ -81,6 +81,31 @@ LocalMatrix *local_matrix_of(void *op)
 	return it == g_local_matrices.end() ? nullptr : it->second;
 }
 
+// side table: PCSHELL context -> how its operator applies asynchronous sweeps (the C struct is public ABI and has
+// no field for it).  -1: follow the process-wide choice.  Filled by setup_blasted_stack, read at every compute().
+struct NodeMode {
+	int mode = -1;
+	bool fixed_outer = false;  // some KSP between this PC and the top of the tree assumes a fixed preconditioner
+	std::string outer_type;    // ... the outermost such KSP's type
+};
+std::map<const Blasted_data *, NodeMode> g_node_modes;
+
+/// Krylov methods that tolerate a preconditioner which changes from one application to the next (and the
+/// non-Krylov ones: a single application, Richardson)
+bool ksp_tolerates_variable_pc(KSP ksp, std::string &type)
+{
+	KSPType kt = NULL;
+	if (KSPGetType(ksp, &kt) || !kt)
+		return true;
+	type = kt;
+	static const char *const flexible[] = {"fgmres", "gcr", "richardson", "preonly", "fcg", "pipefgmres", "pipefcg",
+	                                       "pipegcr", "fbcgs", "fbcgsr"};
+	for (const char *f : flexible)
+		if (type == f)
+			return true;
+	return false;
+}
+
 /// The value array of the rank-local matrix, through the accessor of its type
 PetscErrorCode get_values(Mat A, const int bs, const PetscScalar **vals)
 {
@@ -413,6 +438,7 @@ void destroyBlastedDataList(Blasted_data_list *const b)
 	while (b->ctxlist != NULL) {
 		Blasted_data *node = b->ctxlist;
 		b->ctxlist = node->next;
+		g_node_modes.erase(node);
 		delete static_cast<PrecInfoList *>(node->infolist);
 		delete node;
 		b->size--;
@@ -474,6 +500,10 @@ PetscErrorCode compute_preconditioner_blasted(PC pc)
 	{
 		const StopWatch sw;
 		BlastedPreconditioner *const precop = reinterpret_cast<BlastedPreconditioner *>(ctx->bprec);
+		{
+			const auto nm = g_node_modes.find(ctx);
+			precop->setSweepMode(nm == g_node_modes.end() ? -1 : nm->second.mode);
+		}
 		const PrecInfo pinfo = precop->compute();  // values H2D + factorisation on the GPU
 		if (ctx->compute_precinfo)
 			static_cast<PrecInfoList *>(ctx->infolist)->infolist.push_back(pinfo);
@@ -616,36 +646,47 @@ PetscErrorCode setup_localpreconditioner_blasted(KSP ksp, Blasted_data *const bc
 }
 
 /// Not a reference option: -blasted_sweep_mode async|deterministic|exact chooses how the asynchronous types (ilu0,
-/// sgs) apply their sweeps (operators.cpp, HipOperator::sweep_mode; default async = the reference's chaotic sweeps).
-/// And a notice, once per set-up, when chaotic sweeps meet an outer Krylov method that assumes a fixed
-/// preconditioner: on this GPU the operator differs from one application to the next far more than under the
-/// reference's few threads ("Which outer solver each mode supports").
-static PetscErrorCode sweep_mode_option_and_notice(KSP ksp, const Blasted_data_list *const bctx)
+/// sgs) of THIS list apply their sweeps (operators.hpp, SRPreconditioner::setSweepMode).  Without the option, and
+/// without a process-wide choice (BLASTED_HIP_SWEEP_MODE, detail::set_sweep_mode), the mode follows the KSP tree:
+/// the reference's chaotic sweeps (async) where every Krylov method above the PC takes a preconditioner that
+/// changes between applications (fgmres, gcr, richardson, preonly, ...), and the deterministic (synchronous) sweeps
+/// where one of them assumes a fixed operator (PETSc's default gmres, bcgs, cg): on this GPU the chaotic sweeps
+/// differ from one application to the next far more than under the reference's few threads, and few sweeps on a
+/// large subdomain make such a method stall or diverge ("Which outer solver each mode supports").
+static PetscErrorCode sweep_mode_option(const Blasted_data_list *const bctx)
 {
 	char mstr[BLASTED_OPT_STRLEN];
 	PetscBool set = PETSC_FALSE;
 	PetscOptionsGetString(NULL, NULL, "-blasted_sweep_mode", mstr, BLASTED_OPT_STRLEN, &set);
-	if (set)
-		blasted::detail::set_sweep_mode(mstr);  // (throws std::invalid_argument on anything else, like a bad -blasted_pc_type)
-	bool chaotic = false;  // a type whose APPLICATION runs asynchronous sweeps
-	for (const Blasted_data *node = bctx->ctxlist; node != NULL; node = node->next)
-		chaotic = chaotic || node->prectype == BLASTED_ILU0 || node->prectype == BLASTED_SFILU0 ||
-		          node->prectype == BLASTED_SGS;
-	if (!chaotic || std::strcmp(blasted::detail::sweep_mode_name(), "async") != 0)
-		return 0;
-	KSPType kt = NULL;
-	PetscErrorCode ierr = KSPGetType(ksp, &kt); CHKERRQ(ierr);
-	if (!kt)
-		return 0;
-	static const char *const flexible[] = {"fgmres", "gcr", "richardson", "preonly", "fcg", "pipefgmres", "pipefcg",
-	                                       "pipegcr", "fbcgs", "fbcgsr", "pipefcg"};
-	for (const char *f : flexible)
-		if (std::strcmp(kt, f) == 0)
-			return 0;
-	std::printf("setup_blasted_stack(): NOTE: -ksp_type %s assumes a fixed preconditioner, and the asynchronous sweeps of "
-	            "this backend are a different operator at every application; with few sweeps on a large subdomain "
-	            "the outer iteration can stall or diverge.  Use a flexible method (fgmres, gcr), or "
-	            "-blasted_sweep_mode deterministic (synchronous sweeps) / exact (level-scheduled solves).\n", kt);
+	int asked = -1;
+	if (set) {
+		try {
+			asked = blasted::detail::sweep_mode_from_string(mstr);
+		} catch (const std::invalid_argument &e) {  // never let an exception unwind into a C caller
+			std::fprintf(stderr, "setup_blasted_stack(): -blasted_sweep_mode %s: %s\n", mstr, e.what());
+			SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_WRONG, "-blasted_sweep_mode must be async, deterministic or exact");
+		}
+	}
+	const bool process_choice = blasted::detail::sweep_mode_is_explicit();
+	bool told = false;
+	for (const Blasted_data *node = bctx->ctxlist; node != NULL; node = node->next) {
+		NodeMode &nm = g_node_modes[node];
+		const bool chaotic = node->prectype == BLASTED_ILU0 || node->prectype == BLASTED_SFILU0 ||
+		                     node->prectype == BLASTED_SGS;  // types whose APPLICATION runs asynchronous sweeps
+		if (asked >= 0)
+			nm.mode = asked;
+		else if (process_choice || !chaotic || !nm.fixed_outer)
+			nm.mode = -1;
+		else {
+			nm.mode = blasted::detail::sweep_mode_from_string("deterministic");
+			if (!told)
+				std::printf("setup_blasted_stack(): -ksp_type %s assumes a fixed preconditioner: the %s sweeps are "
+				            "applied in the deterministic (synchronous) mode.  -blasted_sweep_mode async gives the "
+				            "reference's chaotic sweeps (flexible methods: fgmres, gcr), exact the level-scheduled "
+				            "solves.\n", nm.outer_type.c_str(), node->prectype == BLASTED_SGS ? "sgs" : "ilu0");
+			told = true;
+		}
+	}
 	return 0;
 }
 
@@ -655,7 +696,7 @@ PetscErrorCode setup_blasted_stack(KSP ksp, Blasted_data_list *const bctx)
 	bctx->bfactory = (void *)factory;
 	bctx->_defaultfactory = 1;
 	PetscErrorCode ierr = setup_blasted_stack_ext(ksp, factory, bctx); CHKERRQ(ierr);
-	return sweep_mode_option_and_notice(ksp, bctx);
+	return sweep_mode_option(bctx);
 }
 
 void computeTotalTimes(Blasted_data_list *const bctv)
@@ -671,10 +712,24 @@ void computeTotalTimes(Blasted_data_list *const bctv)
 
 }  // extern "C"
 
+static int walk_ksp_tree(KSP ksp, const BlastedFactory *const fctry, Blasted_data_list *const bctv, NodeMode outer);
+
 int setup_blasted_stack_ext(KSP ksp, const BlastedFactory *const fctry, Blasted_data_list *const bctv)
+{
+	return walk_ksp_tree(ksp, fctry, bctv, NodeMode());
+}
+
+static int walk_ksp_tree(KSP ksp, const BlastedFactory *const fctry, Blasted_data_list *const bctv, NodeMode outer)
 {
 	PC pc;
 	PetscErrorCode ierr = KSPGetPC(ksp, &pc); CHKERRQ(ierr);
+	{
+		std::string type;
+		if (!ksp_tolerates_variable_pc(ksp, type) && !outer.fixed_outer) {
+			outer.fixed_outer = true;
+			outer.outer_type = type;
+		}
+	}
 	auto is = [&](const char *type, PetscBool *flag) {
 		return PetscObjectTypeCompare((PetscObject)pc, type, flag);
 	};
@@ -698,7 +753,7 @@ int setup_blasted_stack_ext(KSP ksp, const BlastedFactory *const fctry, Blasted_
 		}
 		if (nlocal != 1)
 			SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_WRONGSTATE, "Only one subdomain per rank is supported.");
-		ierr = setup_blasted_stack_ext(subksp[0], fctry, bctv); CHKERRQ(ierr);
+		ierr = walk_ksp_tree(subksp[0], fctry, bctv, outer); CHKERRQ(ierr);
 	} else if (ismg || isgamg) {
 		ierr = KSPSetUp(ksp); CHKERRQ(ierr);
 		ierr = PCSetUp(pc); CHKERRQ(ierr);
@@ -707,22 +762,23 @@ int setup_blasted_stack_ext(KSP ksp, const BlastedFactory *const fctry, Blasted_
 		for (PetscInt lvl = 1; lvl < nlevels; lvl++) {
 			KSP smoother;
 			ierr = PCMGGetSmoother(pc, lvl, &smoother); CHKERRQ(ierr);
-			ierr = setup_blasted_stack_ext(smoother, fctry, bctv); CHKERRQ(ierr);
+			ierr = walk_ksp_tree(smoother, fctry, bctv, outer); CHKERRQ(ierr);
 		}
 		KSP coarse;
 		ierr = PCMGGetCoarseSolve(pc, &coarse); CHKERRQ(ierr);
-		ierr = setup_blasted_stack_ext(coarse, fctry, bctv); CHKERRQ(ierr);
+		ierr = walk_ksp_tree(coarse, fctry, bctv, outer); CHKERRQ(ierr);
 	} else if (isksp) {
 		ierr = KSPSetUp(ksp); CHKERRQ(ierr);
 		ierr = PCSetUp(pc); CHKERRQ(ierr);
 		KSP sub;
 		ierr = PCKSPGetKSP(pc, &sub); CHKERRQ(ierr);
-		ierr = setup_blasted_stack_ext(sub, fctry, bctv); CHKERRQ(ierr);
+		ierr = walk_ksp_tree(sub, fctry, bctv, outer); CHKERRQ(ierr);
 	} else if (isshell) {
 		std::printf("setup_blasted_stack(): Found valid parent KSP for BLASTed.\n");
 		appendBlastedDataContext(bctv, newBlastedDataContext());
 		bctv->ctxlist->bfactory = bctv->bfactory ? bctv->bfactory : (void *)fctry;
 		ierr = setup_localpreconditioner_blasted(ksp, bctv->ctxlist); CHKERRQ(ierr);
+		g_node_modes[bctv->ctxlist] = outer;
 	}
 	return ierr;
 }
@@ -732,6 +788,6 @@ int setup_blasted_stack_ext(KSP ksp, const FactoryBase<double, int> &factory, Bl
 {
 	bctx->bfactory = (void *)&factory;
 	PetscErrorCode ierr = ::setup_blasted_stack_ext(ksp, &factory, bctx); CHKERRQ(ierr);
-	return sweep_mode_option_and_notice(ksp, bctx);
+	return sweep_mode_option(bctx);
 }
 }  // namespace blasted

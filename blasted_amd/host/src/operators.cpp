@@ -97,6 +97,16 @@ void set_sweep_mode(const char *m)
 	g_sweep_mode_override = (m && *m) ? sweep_mode_from_string(m) : -1;
 }
 
+bool sweep_mode_is_explicit()
+{
+	if (g_sweep_mode_override >= 0)
+		return true;
+	for (const char *v : {"BLASTED_HIP_EXACT_APPLY", "BLASTED_HIP_SYNC_SWEEPS", "BLASTED_HIP_SWEEP_MODE"})
+		if (std::getenv(v))
+			return true;
+	return false;
+}
+
 const char *sweep_mode_name()
 {
 	switch (HipOperator::sweep_mode()) {
@@ -370,7 +380,7 @@ void AsyncBlockSGS_SRPreconditioner<scalar, index, bs, stor>::apply_at(const sca
 	if (!op)
 		throw std::runtime_error("SGS preconditioner: apply() before compute()");
 	HipOperator::check(blasted_hip_sgs_apply(op->get(), r, z, napplysweeps, (int)ainit,
-	                                         HipOperator::sweep_mode(), loc));
+	                                         this->sweepMode(), loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>
@@ -483,7 +493,7 @@ void AsyncBlockILU0_SRPreconditioner<scalar, index, bs, stor>::apply_at(const sc
 		throw std::runtime_error(" scalar_ilu0_apply: Invalid init type!");  // src/solverops_ilu0.cpp:125-126
 	const int sweeps = threadedapply ? napplysweeps : BLASTED_SEQUENTIAL_SYMBOL;
 	HipOperator::check(blasted_hip_ilu0_apply(op->get(), r, z, sweeps, (int)applyinittype,
-	                                          HipOperator::sweep_mode(), loc));
+	                                          this->sweepMode(), loc));
 }
 
 template <typename scalar, typename index, int bs, StorageOptions stor>

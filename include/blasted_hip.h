@@ -161,6 +161,12 @@ int blasted_hip_level_stats(blasted_hip_prec p, long *out4);
  * solves; at most one per array unless tuning "copies=both"), bytes of caller-owned host memory page-locked
  * through blasted_hip_host_register (process-wide) }.  Borrowed device arrays are not counted. */
 int blasted_hip_memory_stats(blasted_hip_prec p, long *out4);
+/* Class-aware placement of the sweeps' large buffers (process-wide counters; DESIGN.md "Address classes"): the
+ * triangle copies the asynchronous sweeps stream are built from 2 GiB pieces that are checked, one by one, not to
+ * share their HBM address class with the vector the sweep writes.  out5 = { buffers built that way, pieces kept,
+ * pieces turned down (wrong class), pieces kept unchecked because the search had already held back a whole class
+ * (expected: 0), probe timings taken }.  Tuning "placement=0" / BLASTED_HIP_PLACEMENT=0 switches it off. */
+int blasted_hip_placement_stats(long *out5);
 /* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
  * inside a level), level_ptr[nlevels+1] */
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr);

@@ -460,6 +460,10 @@ int orc_ilu0_factorize(const orc_bsr *m, const int *posptr, const int *lowerp, c
 	const long nv = (long)m->browptr[m->nbrows] * bs2;
 	if (bs < 1 || bs > ORC_MAXBS || chunk < 1)
 		return -1;
+	/* ORC_KEEP_DIAG (tests): leave the diagonal blocks as the sweeps iterate on them -- the form the reference's own
+	 * fixed-point tests compare (tests/solverops/async_ilu_convergence.cpp drives the kernels and never inverts) */
+	const int keep_diag = init_type & ORC_KEEP_DIAG;
+	init_type &= ~ORC_KEEP_DIAG;
 
 	if (scale)
 		orc_scaling_vector(m, scale);
@@ -524,7 +528,7 @@ int orc_ilu0_factorize(const orc_bsr *m, const int *posptr, const int *lowerp, c
 		precinfo[2] = dd[3]; /* upper min */
 	}
 
-	if (bs > 1) {
+	if (bs > 1 && !keep_diag) {
 		/* async_blockilu_factor.cpp:143-146 */
 #pragma omp parallel for
 		for (int irow = 0; irow < m->nbrows; irow++) {

@@ -50,6 +50,7 @@ enum { ORC_GS_SERIAL = 0,    /* in-place, in order: the reference at OMP_NUM_THR
 
 /* include/async_initialization_decl.hpp:15-34 (same numeric values) */
 enum { ORC_INIT_F_ZERO = 0, ORC_INIT_F_ORIGINAL = 1, ORC_INIT_F_SGS = 2, ORC_INIT_F_NONE = 3 };
+#define ORC_KEEP_DIAG 256 /* or-ed into init_type: orc_ilu0_factorize skips the final inversion of the diagonal blocks */
 enum { ORC_INIT_A_ZERO = 0, ORC_INIT_A_JACOBI = 1, ORC_INIT_A_NONE = 2 };
 
 int orc_num_threads(void);

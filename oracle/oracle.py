@@ -135,8 +135,10 @@ def block_inverse(a, bs, rowmajor=False):
 
 
 def ilu0_factorize(m, plist=None, nbuildsweeps=1, chunk=256, mode=GS_SERIAL, init=INIT_F_ORIGINAL,
-                   usescale=False, iluvals=None, compute_info=False):
-    """-> dict(iluvals, scale, precinfo).  iluvals (optional) is the warm start for INIT_F_NONE."""
+                   usescale=False, iluvals=None, compute_info=False, invert_diag=True):
+    """-> dict(iluvals, scale, precinfo).  iluvals (optional) is the warm start for INIT_F_NONE.
+    invert_diag=False leaves the diagonal blocks as the sweeps iterate on them (the reference's driver inverts them
+    at the end of a block factorisation, src/async_blockilu_factor.cpp:143-146; its fixed-point tests do not)."""
     M = _Mat(m)
     if plist is None:
         plist = ilu_positions(m)
@@ -145,7 +147,8 @@ def ilu0_factorize(m, plist=None, nbuildsweeps=1, chunk=256, mode=GS_SERIAL, ini
     scale = np.zeros(M.n) if usescale else None
     info = np.zeros(6) if compute_info else None
     rc = lib().orc_ilu0_factorize(M.ref, _ptr(posptr), _ptr(lowerp), _ptr(upperp), int(nbuildsweeps),
-                                  int(chunk), int(mode), int(init), _ptr(ilu), _ptr(scale), _ptr(info))
+                                  int(chunk), int(mode), int(init) | (0 if invert_diag else 256), _ptr(ilu), _ptr(scale),
+                                  _ptr(info))
     if rc != 0:
         raise ValueError("orc_ilu0_factorize: invalid argument")
     return {"iluvals": ilu, "scale": scale, "precinfo": info}

@@ -113,31 +113,98 @@ def test_pcshell_pinned_value_array(tmp_path):
     assert np.array_equal(plain["z"], pinned["z"]) and np.array_equal(plain["z2"], pinned["z2"])
 
 
-def test_pcshell_sweep_mode_option_and_notice(tmp_path):
-    """-blasted_sweep_mode (not a reference option) chooses how ilu0 / sgs apply their sweeps; the default is the
-    reference's chaotic sweeps, and setup_blasted_stack says so when the outermost KSP is a method that assumes a
-    fixed preconditioner (PETSc's default gmres).  `deterministic` = synchronous sweeps: the oracle's, to 1e-12."""
+def test_pcshell_sweep_mode_follows_the_ksp_tree(tmp_path):
+    """-blasted_sweep_mode (not a reference option) chooses how ilu0 / sgs apply their sweeps.  Without it the glue
+    follows the KSP tree: under a Krylov method that assumes a fixed preconditioner (PETSc's default
+    gmres, bcgs, cg) the sweeps are the deterministic (synchronous) ones -- the oracle's, to 1e-10 -- and
+    setup_blasted_stack says so; under a flexible method (fgmres, gcr, richardson) they are the reference's chaotic
+    sweeps.  A mistyped mode is a PETSc error code, not an exception through the C caller."""
     m = matrix("baij")
     r = W.rhs_vector(m["nbrows"] * 4)
-    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
-    _, _, res = run(tmp_path, opts)
-    assert "NOTE: -ksp_type gmres assumes a fixed preconditioner" in res.stdout
-    _, _, res = run(tmp_path, opts + ["-ksp_type", "fgmres"])
-    assert "NOTE:" not in res.stdout
-    _, _, res = run(tmp_path, ["-blasted_pc_type", "seqilu0", "-blasted_async_sweeps", "1,1"] + ASYNC_OPTS)
-    assert "NOTE:" not in res.stdout   # exact passes: a fixed operator
-    _, vecs, res = run(tmp_path, opts + ["-blasted_sweep_mode", "deterministic"])
-    assert "NOTE:" not in res.stdout
-    # (the factorisation sweeps stay asynchronous in this mode: build far past the fixed point, compare the apply)
     fexact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
-    _, vecs, _ = run(tmp_path, ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,3"] + ASYNC_OPTS +
-                     ["-blasted_sweep_mode", "deterministic"])
-    assert rel(vecs["z"], O.ilu0_apply(m, fexact, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)) < 1e-10
-    _, vecs, _ = run(tmp_path, ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,3"] + ASYNC_OPTS +
-                     ["-blasted_sweep_mode", "exact"])
-    assert rel(vecs["z"], O.ilu0_apply(m, fexact, r, 1, mode=O.GS_SERIAL)) < 1e-10
-    _, _, res = run(tmp_path, opts + ["-blasted_sweep_mode", "bogus"], expect_rc=3)
-    assert "sweep mode must be" in res.stderr
+    zsync = O.ilu0_apply(m, fexact, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)
+    zexact = O.ilu0_apply(m, fexact, r, 1, mode=O.GS_SERIAL)
+    # (the factorisation sweeps stay asynchronous in every mode: build far past the fixed point, compare the apply)
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "40,3"] + ASYNC_OPTS
+    notice = "assumes a fixed preconditioner: the ilu0 sweeps are applied in the deterministic"
+    _, vecs, res = run(tmp_path, opts)                      # the stub's default -ksp_type is PETSc's: gmres
+    assert "-ksp_type gmres " + notice in res.stdout
+    assert rel(vecs["z"], zsync) < 1e-10
+    zdet = vecs["z"]
+    _, vecs, res = run(tmp_path, opts + ["-ksp_type", "bcgs"])
+    assert "-ksp_type bcgs " + notice in res.stdout and rel(vecs["z"], zsync) < 1e-10
+    for flexible in ("fgmres", "gcr", "richardson"):
+        _, vecs, res = run(tmp_path, opts + ["-ksp_type", flexible])
+        assert "fixed preconditioner" not in res.stdout
+        # three chaotic sweeps: between the synchronous sweeps and the exact solves, and not the synchronous bits
+        assert np.linalg.norm(vecs["z"] - zexact) <= 1.05 * np.linalg.norm(zsync - zexact)
+        assert not np.array_equal(vecs["z"], zdet)
+    _, vecs, res = run(tmp_path, opts + ["-blasted_sweep_mode", "async"])   # an explicit choice is kept, quietly
+    assert "fixed preconditioner" not in res.stdout
+    assert np.linalg.norm(vecs["z"] - zexact) <= 1.05 * np.linalg.norm(zsync - zexact)
+    _, vecs, res = run(tmp_path, opts, env={"BLASTED_HIP_SWEEP_MODE": "async"})   # so is a process-wide one
+    assert "fixed preconditioner" not in res.stdout
+    _, _, res = run(tmp_path, ["-blasted_pc_type", "seqilu0", "-blasted_async_sweeps", "1,1"] + ASYNC_OPTS)
+    assert "fixed preconditioner" not in res.stdout   # exact passes: a fixed operator already
+    _, vecs, res = run(tmp_path, opts + ["-blasted_sweep_mode", "deterministic", "-ksp_type", "fgmres"])
+    assert "fixed preconditioner" not in res.stdout and rel(vecs["z"], zsync) < 1e-10
+    _, vecs, _ = run(tmp_path, opts + ["-blasted_sweep_mode", "exact"])
+    assert rel(vecs["z"], zexact) < 1e-10
+    _, _, res = run(tmp_path, opts + ["-blasted_sweep_mode", "bogus"], expect_rc=10 + 62)  # PETSC_ERR_ARG_WRONG
+    assert "sweep mode must be" in res.stderr and "terminate" not in res.stderr
+
+
+def write_petsc_mat(path, m):
+    """scalar CSR dict -> PETSc binary Mat (big-endian: classid, M, N, nnz, row lengths, columns, values)"""
+    assert m["bs"] == 1
+    rp = np.asarray(m["browptr"], dtype=np.int64)
+    with open(path, "wb") as f:
+        np.array([1211216, m["nbrows"], m["nbrows"], m["nnzb"]], dtype=">i4").tofile(f)
+        (rp[1:] - rp[:-1]).astype(">i4").tofile(f)
+        np.asarray(m["bcolind"]).astype(">i4").tofile(f)
+        np.asarray(m["vals"]).astype(">f8").tofile(f)
+
+
+def write_petsc_vec(path, v):
+    with open(path, "wb") as f:
+        np.array([1211214, v.size], dtype=">i4").tofile(f)
+        v.astype(">f8").tofile(f)
+
+
+def test_pcshell_default_options_converge_under_bcgs_on_a_mid_size_grid(tmp_path):
+    """an out-of-the-box user (-pc_type shell under PETSc's non-flexible default Krylov methods, no
+    -blasted_sweep_mode) must get a converging solve.  Poisson 48^3 (110 592 rows), ilu0 with the reference's 3+3
+    sweeps, the driver's right-preconditioned BiCGStab: with default options the glue picks the deterministic sweeps
+    and the solve reaches 1e-8; the iteration count is the one the explicit deterministic mode gives."""
+    m = W.poisson3d(50, 1, grid="uniform")
+    n = m["nbrows"]
+    xs = np.sin(0.01 * np.arange(n)) + 1.0
+    import scipy.sparse as sp
+    A = sp.csr_matrix((m["vals"], m["bcolind"], m["browptr"]), shape=(n, n))
+    mat, bf, xf = str(tmp_path / "p48.pmat"), str(tmp_path / "p48_b.pvec"), str(tmp_path / "p48_x.pvec")
+    write_petsc_mat(mat, m)
+    write_petsc_vec(bf, A @ xs)
+    write_petsc_vec(xf, xs)
+
+    def solve(extra, env=None):
+        out = str(tmp_path / "s")
+        cmd = [DRIVER, "--mat_file", mat, "--mat_type", "aij", "--out", out, "--b_file", bf, "--x_file", xf,
+               "--solver_tol", "1e-8", "--max_iter", "300", "--", "-pc_type", "bjacobi", "-sub_pc_type", "shell",
+               "-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS + extra
+        e = {k: v for k, v in os.environ.items() if not k.startswith("BLASTED_HIP_S") and k != "BLASTED_HIP_EXACT_APPLY"}
+        e.update(env or {})
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        rep = dict(line.split(" = ", 1) for line in r.stdout.splitlines() if " = " in line)
+        return int(rep["solve_iterations"]), float(rep["solve_relres"]), float(rep["solve_error_l2"]), r.stdout
+
+    for ksp in ([], ["-ksp_type", "bcgs"]):
+        its, relres, err, text = solve(ksp)
+        assert "applied in the deterministic" in text
+        assert relres < 1e-8 and its < 300, (its, relres)
+        assert err < 1e-5 * np.linalg.norm(xs)
+    its_det, relres_det, _, _ = solve(["-blasted_sweep_mode", "deterministic"])
+    assert (its_det, relres_det) == (its, relres)   # the same fixed operator: the same iteration, bit for bit
 
 
 def test_pcshell_ilu0_scaled_with_info(tmp_path):

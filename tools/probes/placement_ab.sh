@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU box: the headline configuration in N fresh processes with the class-aware placement off / quick / thorough.
+# usage: tools/probes/placement_ab.sh <out.txt> [N=4] [variants="1 0 2"]
+OUT=$1; N=${2:-4}; VARS=${3:-"1 0 2"}
+echo "# bench.py --config 2 --steps 10 --warmup 3 in fresh processes: lower / upper sweep ms, fraction of 8 TB/s of the upper sweep, sweeps/s" > $OUT
+for i in $(seq 1 $N); do
+  for pl in $VARS; do
+    t0=$(date +%s.%N)
+    BLASTED_HIP_TRACE_PLACEMENT=1 BLASTED_HIP_PLACEMENT=$pl timeout -k 10 200 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --live-traffic off 2>$OUT.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; pl = d.get('placement', {})
+print('placement=$pl process %2d: lower %.3f ms  upper %.3f ms  frac %.3f  value %.1f  | pieces %s turned down %s unchecked %s probes %s' % ($i, r['lower_ms'], r['upper_ms'], r['frac'], d['value'], pl.get('pieces'), pl.get('turned_down'), pl.get('unchecked'), pl.get('probes')))" >> $OUT || exit 1
+    grep "placed " $OUT.err | head -4 | cut -c1-220 >> $OUT
+    echo "   (process wall time $(echo "$(date +%s.%N) - $t0" | bc) s)" >> $OUT
+  done
+done
+rm -f $OUT.err
+cat $OUT
