@@ -40,10 +40,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 CONFIGS = {
     1: dict(workload="poisson3d_64_csr_async_ilu0_apply", gen="poisson", n=64, bs=1, grid="chebyshev",
             op="ilu_apply", sweeps=3, build=3, cpu_n=64),
+    # cpu_n: BASELINE.md 3's stated fall-back size for the CPU side (192^3); cpu_n_small: used instead when setting the
+    # 192^3 sample up would not fit the time budget of a default run (cpu_baseline says which one ran)
     2: dict(workload="poisson3d_256_bs4_async_block_ilu0_apply", gen="poisson", n=256, bs=4, grid="uniform",
-            op="ilu_apply", sweeps=3, build=3, cpu_n=96),
+            op="ilu_apply", sweeps=3, build=3, cpu_n=192, cpu_n_small=96),
     3: dict(workload="poisson3d_256_bs4_async_block_sgs_relaxation", gen="poisson", n=256, bs=4, grid="uniform",
-            op="sgs_relax", sweeps=5, build=3, cpu_n=96),
+            op="sgs_relax", sweeps=5, build=3, cpu_n=192, cpu_n_small=96),
     4: dict(workload="unstructured_126_bs5_async_block_ilu0_apply", gen="unstructured", n=126, bs=5, grid="-",
             op="ilu_apply", sweeps=3, build=3, cpu_n=40),
     5: dict(workload="poisson3d_100_bs8_block_ilu0_apply", gen="poisson", n=100, bs=8, grid="uniform",
@@ -51,8 +53,13 @@ CONFIGS = {
 }
 
 
-def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed=0):
-    """compulsory bytes, every array touched once per sweep, from the pattern's counts."""
+def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed=0, nfixed_operands=None):
+    """compulsory bytes, every array touched once per sweep, from the pattern's counts.
+    nfixed = upper blocks without position pairs (in-place factorisation sweeps leave them alone); nfixed_operands = how
+    many of THOSE are read as the u_kj operand of some other block's pair (default: all of them -- on a 7-point pattern
+    every upper block is an operand of the diagonal block below it)."""
+    if nfixed_operands is None:
+        nfixed_operands = nfixed
     B, S, I = 8 * bs * bs, 8 * bs, 4
     lower = nnzl * (B + I) + 2 * nb * I + 3 * nb * S
     upper = (nnzu + nb) * B + nnzu * I + 2 * nb * I + 3 * nb * S
@@ -66,10 +73,14 @@ def pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed=0):
         # what an in-place sweep TOUCHES once the upper blocks without position pairs hold their value (all sweeps
         # after INIT_F_ORIGINAL, tuning factorskip=1): their matrix block is not read, their factor block neither
         # read nor written; every index array is still walked
-        "factor_sweep_touched": 3 * (nnzb - nfixed) * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
+        # ... but every fixed block that is the u_kj of a pair is still READ once (perfect-cache rule: each block once per
+        # sweep, however many pairs name it); the diagonal blocks the lower updates multiply with are among the blocks
+        # already counted
+        "factor_sweep_touched": (3 * (nnzb - nfixed) + nfixed_operands) * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
         # the FIRST sweep of an asynchronous build at bs >= 2 (round 3: the initialisation pass is fused into it): the
         # matrix is both right-hand side and iterate (read once), every factor block is written
-        "factor_sweep_fused_first": 2 * nnzb * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
+        # (+ a row's own finished lower blocks, read back from the factor: FactorArgs::lrow_fresh)
+        "factor_sweep_fused_first": (2 * nnzb + nnzl) * B + 2 * nnzb * I + 2 * nb * I + 2 * npairs * I,
         "spmv": nnzb * (B + I) + (nb + 1) * I + 2 * nb * S,
         "nbrows": nb, "nnzb": nnzb, "nnzl": nnzl, "nnzu": nnzu, "pairs": npairs, "fixed_upper": nfixed,
     }
@@ -81,7 +92,7 @@ def algorithmic_bytes(n, bs):
     nnzb = 7 * n ** 3 - 6 * n ** 2
     nnzl = 3 * n ** 3 - 3 * n ** 2
     # (a 7-point row's three upper blocks have no position pairs: only diagonal blocks do)
-    return pattern_bytes(nb, nnzb, nnzl, nnzl, nnzl, bs, nfixed=nnzl)
+    return pattern_bytes(nb, nnzb, nnzl, nnzl, nnzl, bs, nfixed=nnzl, nfixed_operands=nnzl)
 
 
 def matrix_counts(m):
@@ -103,22 +114,32 @@ def unit_of(op, ab):
             "factor": (ab["factor_sweep"], ab["factor_sweep"], "lower")}[op]
 
 
-def cpu_baseline(cfg, op, sweeps, full_unit_bytes, units_per_call, budget_s=12.0):
-    """The oracle's threaded port of the reference loop nest (omp for schedule(dynamic,256) nowait),
-    timed on this box's host cores on a bounded sample of the same workload (a smaller grid of the same
-    generator), scaled to the metric's unit by algorithmic bytes."""
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+def cpu_sample(cfg, op, nsample, sweeps, budget_s, dev=None):
+    """One timed sample of the oracle's threaded loop nest: (seconds per call, calls, unit bytes, description, set-up s).
+    Large Poisson samples are GENERATED on the GPU when there is one (the numpy generator and the oracle's serial
+    factorisation take minutes at 192^3) -- matrix by workloads.poisson3d_device, the factor the sweeps are timed on by
+    the library's exact factorisation, both copied to the host; what is TIMED is the oracle alone."""
     import oracle
     from blasted_amd import workloads
-    # one thread per CPU this process is really granted (affinity mask cut by the cgroup quota): more
-    # threads than that only thrash; the count is what `cores` reports
-    budget = oracle.cpu_budget()
-    oracle.set_num_threads(budget)
-    nsample, bs = cfg["cpu_n"], cfg["bs"]
+    t_setup = time.perf_counter()
+    bs = cfg["bs"]
+    on_device = dev is not None and cfg["gen"] != "unstructured" and nsample >= 128
+    iluvals = None
     if cfg["gen"] == "unstructured":
         m = workloads.to_numpy(workloads.unstructured_bsr(nsample, bs, device="cpu"))
         what = "unstructured %d^3" % nsample
+    elif on_device:
+        from blasted_amd import capi
+        md = workloads.poisson3d_device(nsample, bs, dev, grid=cfg["grid"])
+        if op == "ilu_apply":
+            pg = capi.Prec(dev.index or 0)
+            pg.set_matrix(md)
+            pg.ilu0_factorize(-1)
+            iluvals = pg.get_iluvals()
+            pg.close()
+        m = workloads.to_numpy(md)
+        del md
+        what = "Poisson %d^3 (%s grid; matrix and factor made on the GPU, copied to the host)" % (nsample, cfg["grid"])
     else:
         m = workloads.poisson3d(nsample + 2, bs, grid=cfg["grid"])
         what = "Poisson %d^3 (%s grid)" % (nsample, cfg["grid"])
@@ -126,24 +147,58 @@ def cpu_baseline(cfg, op, sweeps, full_unit_bytes, units_per_call, budget_s=12.0
     kw = {}
     plist = oracle.ilu_positions(m)
     if op == "ilu_apply":
-        kw["iluvals"] = oracle.ilu0_factorize(m, plist, 1, mode=oracle.GS_SERIAL)["iluvals"]
+        kw["iluvals"] = iluvals if iluvals is not None else oracle.ilu0_factorize(m, plist, 1, mode=oracle.GS_SERIAL)["iluvals"]
     elif op == "factor":
         kw["plist"] = plist
     elif op != "spmv":
         kw["dblocks"] = oracle.jacobi_compute(m)
+    t_setup = time.perf_counter() - t_setup
     t1 = oracle.time_op(op, m, r, sweeps, 256, 2, **kw)
     reps = max(3, min(200, int(budget_s / max(t1, 1e-4))))
     t = oracle.time_op(op, m, r, sweeps, 256, reps, **kw)
     nb, nnzb, nnzl, nnzu = matrix_counts(m)
     sample_unit = unit_of(op, pattern_bytes(nb, nnzb, nnzl, nnzu, int(plist[1].size), bs))[0]
+    return t, reps, sample_unit, what, t_setup
+
+
+def cpu_baseline(cfg, op, sweeps, full_unit_bytes, units_per_call, budget_s=12.0, setup_budget_s=150.0, dev=None):
+    """The oracle's threaded port of the reference loop nest (omp for schedule(dynamic,256) nowait), timed on this
+    box's host cores on a bounded sample of the same workload (a smaller grid of the same generator), scaled to the
+    metric's unit by algorithmic bytes.  Configs 2 / 3: BASELINE.md 3's 192^3 when its set-up (numpy generator, position
+    lists, one serial factorisation) fits `setup_budget_s` -- predicted from the 96^3 sample, which always runs first --
+    otherwise the 96^3 sample stands."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    import oracle
+    # one thread per CPU this process is really granted (affinity mask cut by the cgroup quota): more
+    # threads than that only thrash; the count is what `cores` reports
+    budget = oracle.cpu_budget()
+    oracle.set_num_threads(budget)
+    bs = cfg["bs"]
+    small = cfg.get("cpu_n_small")
+    note = ""
+    if small and small < cfg["cpu_n"]:
+        t, reps, sample_unit, what, t_setup = cpu_sample(cfg, op, small, sweeps, min(budget_s, 4.0))
+        # (on the GPU the large sample's set-up is the position lists and two copies: a tenth of the host generator's)
+        predicted = t_setup * (cfg["cpu_n"] / small) ** 3 * (0.1 if dev is not None else 1.0)
+        if predicted <= setup_budget_s:
+            t96 = (t, what)
+            t, reps, sample_unit, what, t_setup2 = cpu_sample(cfg, op, cfg["cpu_n"], sweeps, budget_s, dev)
+            note = "; set-up %.0f s (predicted %.0f s from the %s sample, which ran first: %.1f ms per call)" % (
+                t_setup2, predicted, t96[1], t96[0] * 1e3)
+        else:
+            note = "; the %d^3 sample was NOT run: its set-up was predicted at %.0f s (budget %.0f s)" % (
+                cfg["cpu_n"], predicted, setup_budget_s)
+    else:
+        t, reps, sample_unit, what, _ = cpu_sample(cfg, op, cfg["cpu_n"], sweeps, budget_s)
     return {
         "value": (units_per_call / t) * sample_unit / full_unit_bytes,
         "unit": "sweeps/s", "cores": oracle.num_threads(), "kind": "port",
         "achieved_gbps": sample_unit * units_per_call / t / 1e9,
         "sample": "oracle ASYNC_OMP (reference loop nest, chunk 256) %s on %s bs=%d, %d sweeps per call, "
                   "min of %d calls = %.1f ms, %d OpenMP threads = the CPUs granted to this process (%d hardware "
-                  "threads visible); scaled to the full size by algorithmic bytes" %
-                  (op, what, bs, sweeps, reps, t * 1e3, oracle.num_threads(), os.cpu_count() or 0),
+                  "threads visible); scaled to the full size by algorithmic bytes%s" %
+                  (op, what, bs, sweeps, reps, t * 1e3, oracle.num_threads(), os.cpu_count() or 0, note),
     }
 
 
@@ -240,17 +295,68 @@ def quality_figures(p, capi, torch, r, z, s):
     return out
 
 
+def product_default_block(m, r, z, cfg, s, dev_index, stream, capi, torch, ab):
+    """What a caller gets WITHOUT any of this benchmark's settings: compact copies made when they pay (the 16th
+    application since a factorisation at bs = 4: until then the sweeps read the factor in place) and the quick form of the
+    class-aware placement.  An operator of its own, built and dropped before the measured one."""
+    capi.set_tuning("compactafter=-1")
+    capi.set_tuning("placement=1")
+    p0 = capi.Prec(dev_index, stream)
+    p0.set_matrix(m)
+    p0.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+
+    def timed(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            p0.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    p0.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)     # application 1 (first-touch effects)
+    in_place = timed(10)                                                     # applications 2 .. 11
+    n_before = 1 + 10
+    copies0 = p0.memory_stats()["derived_copies"]
+    switch_ms, guard = None, 0
+    while p0.memory_stats()["derived_copies"] == copies0 and guard < 40:     # ... until the copies are made
+        switch_ms = timed(1)
+        n_before += 1
+        guard += 1
+    timed(3)
+    p0.set_timing(True)
+    p0.get_timing(reset=True)
+    steady = timed(10)
+    tm = p0.get_timing(reset=True)
+    p0.set_timing(False)
+    where = p0.placement_check(r, z)
+    lo = tm["lower_ms"] / max(tm["lower_launches"], 1)
+    up = tm["upper_ms"] / max(tm["upper_launches"], 1)
+    p0.close()
+    torch.cuda.synchronize()
+    return {"in_place_apply_ms": in_place, "in_place_value": s / (in_place * 1e-3),
+            "copies_made_with_application": n_before, "that_application_ms": switch_ms,
+            "steady_apply_ms": steady, "steady_value": s / (steady * 1e-3), "unit": "sweeps/s",
+            "lower_ms": lo, "upper_ms": up, "upper_frac": ab["upper_sweep"] / (up * 1e-3) / 1e9 / HBM_PEAK_GBS if up > 0 else 0.0,
+            "placement": "quick (default)", "where": where,
+            "note": "product defaults (BLASTED_HIP_COMPACT_AFTER / BLASTED_HIP_PLACEMENT unset): applications 2-11 read the "
+                    "factor in place; the application that makes the compact copies also pays the copy pass and the placement "
+                    "search; steady_* is the rate after it.  `value` of this line is the steady state of an operator whose "
+                    "copies were placed by the thorough search (config.placement)"}
+
+
 def fixed_upper_blocks(p, m, gen):
     """Upper blocks without position pairs (what factorskip leaves alone).  A 7-point row: all its upper blocks."""
     nb, nnzb, nnzl, nnzu = matrix_counts(m)
     if gen != "unstructured":
-        return nnzu
+        return nnzu, nnzu
     import numpy as np
-    posptr = p.ilu0_positions()[0]
+    posptr, _, upperp = p.ilu0_positions()
     rp = m["browptr"].cpu().numpy().astype(np.int64)
     col = m["bcolind"].cpu().numpy()
     rowof = np.repeat(np.arange(nb, dtype=np.int64), rp[1:] - rp[:-1])
-    return int(((col > rowof) & (posptr[1:] == posptr[:-1])).sum())
+    fixed = (col > rowof) & (posptr[1:] == posptr[:-1])
+    operand = np.zeros(nnzb, dtype=bool)
+    operand[upperp] = True   # blocks that are the u_kj of some pair
+    return int(fixed.sum()), int((fixed & operand).sum())
 
 
 def short_run(k, dev, stream, capi, workloads, torch, steps=5, warmup=2, reuse=None):
@@ -333,7 +439,8 @@ def reference_side_quality(cfg, capi, workloads, torch, dev, s):
     import numpy as np
     import oracle
     oracle.set_num_threads(oracle.cpu_budget())
-    m = workloads.poisson3d(cfg["cpu_n"] + 2, cfg["bs"], grid=cfg["grid"])
+    nq = cfg.get("cpu_n_small", cfg["cpu_n"])
+    m = workloads.poisson3d(nq + 2, cfg["bs"], grid=cfg["grid"])
     r = workloads.rhs_vector(m["nbrows"] * cfg["bs"])
     f = oracle.ilu0_factorize(m, None, 1, mode=oracle.GS_SERIAL)["iluvals"]
     ze = oracle.ilu0_apply(m, f, r, 1, mode=oracle.GS_SERIAL)
@@ -349,7 +456,7 @@ def reference_side_quality(cfg, capi, workloads, torch, dev, s):
 
     def rho(d):
         return (d[10] / d[s]) ** (1.0 / (10 - s)) if 0 < d[10] < d[s] and s < 10 and d[10] > 1e-14 else None
-    return {"sample": "Poisson %d^3 bs=%d (the cpu_baseline sample)" % (cfg["cpu_n"], cfg["bs"]),
+    return {"sample": "Poisson %d^3 bs=%d" % (nq, cfg["bs"]),
             "threads": oracle.num_threads(),
             "reference_loop_nest": {"distance_after_%d+%d" % (s, s): ref[s], "distance_after_10+10": ref[10],
                                     "contraction_per_sweep": rho(ref)},
@@ -476,6 +583,11 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the short measurements of configurations 3, 4, 5, 1")
     ap.add_argument("--cpu-sample-n", type=int, default=None)
+    ap.add_argument("--placement", default="2", choices=["0", "1", "2"],
+                    help="class-aware placement of the measured operator's triangle copies: 2 thorough (default here), "
+                         "1 quick (the product default), 0 off")
+    ap.add_argument("--no-product-default", action="store_true",
+                    help="skip the product_default block (an extra operator with the product's lazy copies and quick placement)")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic from two rocprofv3 --pmc passes of this command, started before the timed run "
                          "(auto: one-GPU runs when rocprofv3 is there; off: the committed record of profiles/traffic.json)")
@@ -570,18 +682,31 @@ def main():
         z = torch.zeros_like(r)
         sync()
         stream = torch.cuda.current_stream().cuda_stream
+        product_default = None
+        if op == "ilu_apply" and world == 1 and os.environ.get("BLASTED_BENCH_PMC_CHILD") != "1" and not args.no_product_default:
+            try:
+                nb0, nnzb0, nnzl0, nnzu0 = matrix_counts(m)
+                product_default = product_default_block(m, r, z, cfg, s, local_rank, stream, capi, torch,
+                                                        pattern_bytes(nb0, nnzb0, nnzl0, nnzu0, nnzl0, bs))
+            except Exception as e:  # a side figure
+                product_default = {"failed": repr(e)}
+        # the measured operator: the steady state of a long solve (copies made at once) with its triangle copies placed by
+        # the THOROUGH search (every piece in the right address class; a one-time cost of 0.1 ... several seconds that the
+        # quick default search does not spend -- DESIGN.md, address classes)
+        capi.set_tuning("compactafter=0")
+        capi.set_tuning("placement=%s" % args.placement)
         p = capi.Prec(local_rank, stream)
         p.set_matrix(m)
         nb, nnzb, nnzl, nnzu = matrix_counts(m)
         npairs = nnzl
-        nfixed = 0
+        nfixed, nfixed_ops = 0, 0
         if op in ("ilu_apply", "factor"):
             p.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
             npairs = p.ilu0_positions_size()
-            nfixed = fixed_upper_blocks(p, m, cfg["gen"])
+            nfixed, nfixed_ops = fixed_upper_blocks(p, m, cfg["gen"])
         else:
             p.jacobi_compute()
-        ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed)
+        ab = pattern_bytes(nb, nnzb, nnzl, nnzu, npairs, bs, nfixed, nfixed_ops)
         sync()
         step = {
             "ilu_apply": lambda: p.ilu0_apply(r, s, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z),
@@ -637,7 +762,10 @@ def main():
                        "napplysweeps": s, "nbuildsweeps": cfg["build"], "sweep_mode": "async",
                        "row_order_in_chunk": "natural (default)", "grid": cfg["grid"],
                        "compact_copies": "made with the first application (steady state; product default: once they pay, "
-                                         "the 16th application since a factorisation at bs=4)",
+                                         "the 16th application since a factorisation at bs=4 -- see product_default)",
+                       "placement": {"0": "off", "1": "quick (the product default)",
+                                     "2": "thorough (BLASTED_HIP_PLACEMENT=2; the product default is the quick search -- "
+                                          "see product_default)"}[getattr(args, "placement", "2")],
                        "replicas": world,
                        "unit_definition": "one %s = %d algorithmic bytes" % (
                            {"ilu_apply": "L+U sweep pair",
@@ -701,8 +829,13 @@ def main():
                 "lower_ms": tm["lower_ms"] / max(tm["lower_launches"], 1),
                 "upper_ms": tm["upper_ms"] / max(tm["upper_launches"], 1),
                 "other_ms_per_step": tm["other_ms"] / args.steps}
+            if product_default is not None:
+                out["product_default"] = product_default
             out["placement"] = dict(capi.placement_stats(), note="class-aware placement of the triangle copies "
-                                    "(blasted_hip_placement_stats): 2 GiB pieces checked against the vector the sweep writes")
+                                    "(blasted_hip_placement_stats; DESIGN.md, address classes): 1 GiB pieces checked with a "
+                                    "read-beside-write probe against the vectors the sweeps read and write")
+            if op == "ilu_apply":
+                out["placement"]["where"] = p.placement_check(r, z)
             if cache_resident:
                 out["roofline"]["note"] = ("working set %.0f MB: cache-resident, launch-latency bound (%.1f us per step "
                                            "over %d launches); frac is against the HBM peak only for uniformity" % (
@@ -753,8 +886,13 @@ def main():
                                  "frac": tb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else 0.0,
                                  "moved_gbps": (ftraffic["hbm_bytes_per_launch"] / (fms * 1e-3) / 1e9
                                                 if ftraffic and ftraffic.get("hbm_bytes_per_launch") and fms > 0 else None),
+                                 "frac_by_traffic": (ftraffic["hbm_bytes_per_launch"] / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                     if ftraffic and ftraffic.get("hbm_bytes_per_launch") and fms > 0 else None),
+                                 "traffic_over_touched": (ftraffic["hbm_bytes_per_launch"] / tb
+                                                          if ftraffic and ftraffic.get("hbm_bytes_per_launch") else None),
                                  "note": "in-place sweeps leave upper blocks without position pairs alone (their value "
-                                         "is the matrix block): achieved / frac count the bytes the sweeps touch, not "
+                                         "is the matrix block; those that are the u_kj of a pair are still read once as "
+                                         "operands): achieved / frac count the bytes the sweeps touch, not "
                                          "the every-array-once figure; at bs >= 2 the build's first sweep reads the matrix "
                                          "as its iterate and writes every block (the initialisation pass is fused into "
                                          "it), sweep_ms / touched bytes / traffic are averages over the build's sweeps"}
@@ -835,7 +973,7 @@ def main():
             out["other_configs"] = others
         if not dry and world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, op, s, unit_bytes, units_per_step)
+                out["cpu_baseline"] = cpu_baseline(cfg, op, s, unit_bytes, units_per_step, dev=dev)
             except Exception as e:  # the baseline is a reported side figure, never the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -33,7 +33,7 @@ SYMBOLS = [
     "blasted_hip_gs_relax", "blasted_hip_level_schedule", "blasted_hip_level_count",
     "blasted_hip_get_levels", "blasted_hip_level_stats", "blasted_hip_jacobi_relax",
     "blasted_hip_device_synchronize", "blasted_hip_memory_stats", "blasted_hip_host_register",
-    "blasted_hip_host_unregister", "blasted_hip_placement_stats",
+    "blasted_hip_host_unregister", "blasted_hip_placement_stats", "blasted_hip_placement_check",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def lib():
         _lib.blasted_hip_get_levels.argtypes = [vp, vp, vp, vp]
         _lib.blasted_hip_level_stats.argtypes = [vp, vp]
         _lib.blasted_hip_memory_stats.argtypes = [vp, vp]
+        _lib.blasted_hip_placement_check.argtypes = [vp, vp, vp, vp]
         _lib.blasted_hip_host_register.argtypes = [vp, C.c_ulong]
         _lib.blasted_hip_host_unregister.argtypes = [vp]
         _lib.blasted_hip_spmv.argtypes = [vp, vp, vp, ci]
@@ -312,6 +313,14 @@ class Prec:
         ptr = np.zeros(nl + 1, dtype=np.int32)
         _check(lib().blasted_hip_get_levels(self._h, lv.ctypes.data, rows.ctypes.data, ptr.ctypes.data))
         return lv, rows, ptr
+
+    def placement_check(self, r, z):
+        """address classes of the ILU application's buffers against device vectors r, z (include/blasted_hip.h)"""
+        out = (C.c_long * 8)()
+        _check(lib().blasted_hip_placement_check(self._h, _ptr(r), _ptr(z), out))
+        keys = ("lower_pieces", "lower_in_ytemp_class", "lower_in_r_class", "upper_pieces", "upper_in_z_class",
+                "upper_in_ytemp_class", "ytemp_in_r_class", "ytemp_in_z_class")
+        return dict(zip(keys, [int(v) for v in out]))
 
     # -- SpMV
     def spmv(self, x, out=None):

@@ -229,12 +229,26 @@ static int class_fits(void *piece, size_t piece_bytes, const PlaceHint &h, doubl
 // How much device memory a search may hold back while it looks for pieces of the right class (they are released when
 // the buffer is complete).  Consecutive allocations usually come from one class until the driver's free blocks of that
 // class run out, so a search can need tens of GiB -- and the driver's allocation calls take anything from 0.1 ms to
-// seconds each (freed memory is wiped asynchronously): the default is a QUICK search (16 GiB: helps when the driver's
-// free lists are mixed, gives up otherwise and keeps what it got); tuning "placement=2" / BLASTED_HIP_PLACEMENT=2 is the
-// THOROUGH one (up to 200 GiB held back for a moment: the fast mode every time, for long solves on one rank per GPU).
+// seconds each (freed memory is wiped asynchronously).  Bounded by what is free (less a reserve for everybody else on the
+// device) and by time (place_budget_ms).
+// ... and how long: the driver's allocation calls take 0.1 ms when the device is quiet (a search that steps over 64 GiB
+// was seen to take 11 ms) and SECONDS while memory that other processes freed a moment ago is still being wiped.  The
+// default gives a search about fifty applications' worth of time (6 sweeps over the buffer each, at 5 TB/s: 0.5 s for
+// the 8.5 GB upper copy of the 256^3 bs=4 case), then keeps what comes; "placement=2" allows 20 s.
+static double place_budget_ms(size_t bytes)
+{
+	if (g_placement >= 2)
+		return 20000.0;
+	const double ms = (double)bytes * 6e-8;
+	return ms < 15.0 ? 15.0 : ms;
+}
+
+// And what a search holds back it must hand back: the driver wipes released memory (about 30 ms per GiB on these
+// boxes) and the NEXT allocation of the process waits for that -- a search that had stepped over 200 GiB made the
+// allocation after it take 6 s (profiles/r04_placement_ab_unbounded_bytes.txt).  Default: at most 8 GiB.
 static size_t place_budget(size_t bytes)
 {
-	size_t want = g_placement >= 2 ? (size_t)200 << 30 : (size_t)16 << 30;
+	size_t want = g_placement >= 2 ? (size_t)256 << 30 : (size_t)8 << 30;
 	// never more than what is free now, less the buffer itself and a reserve for everybody else on the device
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
@@ -292,6 +306,7 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	std::vector<hipMemGenericAllocationHandle_t> held;  // turned-down pieces and spacers: allocated until the search is over
 	size_t held_bytes = 0;
 	const size_t budget = place_budget(total);
+	const double budget_ms = place_budget_ms(bytes);
 	// Every candidate piece is looked at in an address range of its own (never used again) and only a piece that is kept is
 	// mapped into the buffer: no address is ever mapped twice (see tracked_free for what that is about).
 	const size_t max_tries = total / piece + 2 + budget / piece;
@@ -308,7 +323,7 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	for (size_t at = 0; ok && at < total;) {
 		const size_t sz = total - at < piece ? total - at : piece;
 		// after two misses in a row: step over a larger stretch of the driver's free memory without looking at it
-		if (misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget) {
+		if (misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget && now_ms() - t_start < budget_ms) {
 			size_t sp = (size_t)1 << (30 + (misses < 6 ? misses - 1 : 5));  // 2, 4, 8, 16, 32 GiB
 			while (held_bytes + sp > budget && sp > piece)
 				sp >>= 1;
@@ -329,7 +344,7 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 			break;
 		}
 		char *where = static_cast<char *>(va) + at;
-		const bool may_reject = held_bytes + sz <= budget && tries < max_tries;
+		const bool may_reject = held_bytes + sz <= budget && tries < max_tries && now_ms() - t_start < budget_ms;
 		int rel = 0;
 		if (may_reject) {
 			char *look = scratch + (tries++) * piece;
@@ -1524,10 +1539,17 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->fac_applies, p->fac_nat);
 		if (compact) {
-			set_place_hint(p, nullptr, dr);  // the lower copy in r's class (see place_ytemp) ...
+			// thorough ("placement=2"): the lower copy in r's class, ytemp in neither r's nor z's, the upper copy in ytemp's
+			// (place_ytemp); default: only what costs 10 % when it goes wrong -- the lower copy not in ytemp's class, the
+			// upper copy not in z's (two of three classes will do: a search that holds back little finds them)
+			if (g_placement >= 2)
+				set_place_hint(p, nullptr, dr);
+			else
+				set_place_hint(p, p->ytemp, nullptr);
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
-			place_ytemp(p, dr, dz);          // ... ytemp in neither r's nor z's ...
+			if (g_placement >= 2)
+				place_ytemp(p, dr, dz);
 		}
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y;
@@ -1557,7 +1579,10 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rhs = y;
 		a.descending = 1;
 		if (compact) {
-			set_place_hint(p, nullptr, p->ytemp);  // ... and the upper copy in ytemp's
+			if (g_placement >= 2)
+				set_place_hint(p, nullptr, p->ytemp);
+			else
+				set_place_hint(p, dz, nullptr);
 			const bool fresh = !p->fac_nat.u;
 			compact_args(p, true, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
@@ -2057,6 +2082,49 @@ int blasted_hip_memory_stats(blasted_hip_prec p, long *out4)
 		out4[2] = copies;  // in triangles: two = one copy's worth
 		std::lock_guard<std::mutex> lk(g_pins.mu);
 		out4[3] = g_pins.registered_bytes;
+	});
+}
+
+int blasted_hip_placement_check(blasted_hip_prec p, const double *r, const double *z, long *out8)
+{
+	return guarded([&] {
+		use_device(p);
+		if (!out8 || !r || !z)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "placement_check: null argument");
+		for (int i = 0; i < 8; i++)
+			out8[i] = -1;
+		const size_t nbytes = sizeof(double) * (size_t)p->n();
+		if (!p->ytemp || nbytes < ((size_t)64 << 20))
+			return;  // too small for the probe to tell
+		BHIP_CHECK(hipStreamSynchronize(p->stream));
+		double *sink = dev_alloc<double>(1);
+		auto same = [&](void *piece, size_t bytes, const void *ref) {
+			PlaceHint h;
+			h.same = ref;
+			h.ref_bytes = nbytes;
+			return class_fits(piece, bytes, h, sink, p->stream) > 0;
+		};
+		const LevelSchedule &ns = p->natstore;
+		const size_t bsz = (size_t)p->pat.bs * p->pat.bs * 8, G1 = (size_t)1 << 30;
+		const size_t lb = p->fac_nat.l ? (size_t)ns.nnz_lower * bsz : 0, ub = p->fac_nat.u ? (size_t)ns.nnz_dupper * bsz : 0;
+		out8[0] = out8[1] = out8[2] = out8[3] = out8[4] = out8[5] = 0;
+		for (size_t at = 0; at + ((size_t)256 << 20) <= lb; at += G1) {
+			char *pc = reinterpret_cast<char *>(p->fac_nat.l) + at;
+			const size_t sz = lb - at < G1 ? lb - at : G1;
+			out8[0]++;
+			out8[1] += same(pc, sz, p->ytemp);
+			out8[2] += same(pc, sz, r);
+		}
+		for (size_t at = 0; at + ((size_t)256 << 20) <= ub; at += G1) {
+			char *pc = reinterpret_cast<char *>(p->fac_nat.u) + at;
+			const size_t sz = ub - at < G1 ? ub - at : G1;
+			out8[3]++;
+			out8[4] += same(pc, sz, z);
+			out8[5] += same(pc, sz, p->ytemp);
+		}
+		out8[6] = same(p->ytemp, nbytes, r);
+		out8[7] = same(p->ytemp, nbytes, z);
+		dev_free(sink);
 	});
 }
 

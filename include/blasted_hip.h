@@ -167,6 +167,12 @@ int blasted_hip_memory_stats(blasted_hip_prec p, long *out4);
  * pieces turned down (wrong class), pieces kept unchecked because the search had already held back a whole class
  * (expected: 0), probe timings taken }.  Tuning "placement=0" / BLASTED_HIP_PLACEMENT=0 switches it off. */
 int blasted_hip_placement_stats(long *out5);
+/* Where the buffers of an asynchronous ILU application lie relative to a caller's device vectors r and z (measured
+ * with the address-class probe, about 0.2 s at 256^3 bs=4): out8 = { 1 GiB pieces of the lower triangle copy, how many
+ * of them share ytemp's class (0 wanted: the lower sweeps write ytemp), how many share r's (all wanted: they read r),
+ * pieces of the upper copy, how many share z's class (0 wanted: the upper sweeps write z), how many share ytemp's (all
+ * wanted), ytemp in r's class (0 / 1), ytemp in z's class }; -1 = not applicable (no copies yet, vectors under 64 MiB). */
+int blasted_hip_placement_check(blasted_hip_prec p, const double *r_dev, const double *z_dev, long *out8);
 /* host copies (any may be NULL): level_of_row[nbrows], rows_by_level[nbrows] (stable: ascending row
  * inside a level), level_ptr[nlevels+1] */
 int blasted_hip_get_levels(blasted_hip_prec p, int *level_of_row, int *rows_by_level, int *level_ptr);

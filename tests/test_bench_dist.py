@@ -80,8 +80,19 @@ def test_algorithmic_bytes_match_survey():
     nb, nnzb, nnzl, nnzu = bench.matrix_counts(m)
     assert bench.pattern_bytes(nb, nnzb, nnzl, nnzu, nnzl, 4, nfixed=nnzu) == bench.algorithmic_bytes(6, 4)
     # the bytes an in-place sweep touches once the pair-less upper blocks are left alone: 3 arrays x their blocks less
+    # ... but each of them is still READ once as the u_kj operand of the pair of the diagonal block below it (VERDICT r03
+    # item 3a): every-array-once less the A read and the F write of the fixed blocks
     ab6 = bench.algorithmic_bytes(6, 4)
-    assert ab6["factor_sweep"] - ab6["factor_sweep_touched"] == 3 * nnzu * 128
+    assert ab6["factor_sweep"] - ab6["factor_sweep_touched"] == 2 * nnzu * 128
+    # 256^3 bs=4: 33.6 GB per in-place sweep, 37.9 GB for the fused first sweep of a build (reads A once, writes every
+    # block, reads a row's own lower blocks back); the counters showed 39.06 GB per launch averaged over a 3-sweep build
+    # (profiles/r03z_c2_pmc.json): the touched count of a build is within 15 % of it
+    assert abs(ab["factor_sweep_touched"] - 33.6e9) < 0.1e9 and abs(ab["factor_sweep_fused_first"] - 37.85e9) < 0.1e9
+    build = (ab["factor_sweep_fused_first"] + 2 * ab["factor_sweep_touched"]) / 3
+    assert 0.85 < build / 39.06e9 < 1.0
+    # a pattern whose fixed blocks are not all operands: counted separately
+    pb = bench.pattern_bytes(nb, nnzb, nnzl, nnzu, nnzl, 4, nfixed=nnzu, nfixed_operands=nnzu - 10)
+    assert ab6["factor_sweep_touched"] - pb["factor_sweep_touched"] == 10 * 128
 
 
 def test_live_traffic_picks_the_dominant_kernel_from_a_counter_csv(tmp_path):

@@ -9,9 +9,9 @@ for i in $(seq 1 $N); do
     BLASTED_HIP_TRACE_PLACEMENT=1 BLASTED_HIP_PLACEMENT=$pl timeout -k 10 200 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --live-traffic off 2>$OUT.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; pl = d.get('placement', {})
-print('placement=$pl process %2d: lower %.3f ms  upper %.3f ms  frac %.3f  value %.1f  | pieces %s turned down %s unchecked %s probes %s' % ($i, r['lower_ms'], r['upper_ms'], r['frac'], d['value'], pl.get('pieces'), pl.get('turned_down'), pl.get('unchecked'), pl.get('probes')))" >> $OUT || exit 1
-    grep "placed " $OUT.err | head -4 | cut -c1-220 >> $OUT
-    echo "   (process wall time $(echo "$(date +%s.%N) - $t0" | bc) s)" >> $OUT
+w = pl.get('where', {})
+print('placement=$pl process %2d: lower %.3f ms  upper %.3f ms  frac %.3f  value %.1f  | turned down %s unchecked %s | lower copy: %s/%s pieces in ytemp class, %s in r class; upper copy: %s/%s in z class, %s in ytemp class; ytemp in r/z class: %s/%s' % ($i, r['lower_ms'], r['upper_ms'], r['frac'], d['value'], pl.get('turned_down'), pl.get('unchecked'), w.get('lower_in_ytemp_class'), w.get('lower_pieces'), w.get('lower_in_r_class'), w.get('upper_in_z_class'), w.get('upper_pieces'), w.get('upper_in_ytemp_class'), w.get('ytemp_in_r_class'), w.get('ytemp_in_z_class')))" >> $OUT || exit 1
+    grep "placed " $OUT.err | head -3 | sed -e "s/.*placed/      placed/" | cut -c1-200 >> $OUT
   done
 done
 rm -f $OUT.err
