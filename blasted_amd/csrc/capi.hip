@@ -863,7 +863,17 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 	if (upper && !p->y_in_level_order)
 		return 0;
 	const long n = p->n();
-	double *out = upper ? ensure(p->zperm, n) : ensure(p->yperm, n);
+	double *&mine = upper ? p->zperm : p->yperm;
+	if (!mine) {
+		// the level-ordered iterate this pass WRITES: not in the address class of the triangle copy it streams (placed_alloc)
+		PlaceHint h;
+		h.avoid = view.vals;
+		h.ref_bytes = sizeof(double) * (size_t)n;
+		if (trace_placement())
+			std::fprintf(stderr, "[blasted_hip] level-ordered %s iterate:\n", upper ? "z" : "y");
+		mine = dev_alloc_placed<double>((size_t)n, h, p->stream);
+	}
+	double *out = mine;
 	launch_syncfree_fill(out, n, p->stream);
 	a.vals = view.vals;
 	a.xin = out;
@@ -2366,10 +2376,19 @@ int blasted_hip_set_tuning(const char *spec)
 			set_invert_rowlane(spec[10] != '0');  // eight-lanes-per-block inversion of 5 <= bs <= 8 diagonal blocks
 		else if (spec && std::strncmp(spec, "latestore=", 10) == 0)
 			g_late_store = (spec[10] == '0' || spec[10] == '1' || spec[10] == '2' || spec[10] == '4') ? spec[10] - '0' : 2;  // row steps in flight; 0: stores step by step
+#ifdef BHIP_PROBES
 		else if (spec && std::strncmp(spec, "gatherprobe=", 12) == 0)
 			g_gather_probe = spec[12] - '0';  // measurements only: wrong results (1: sweepodd gathers its own row; 2, 3: store probes of the interleaved bs=4 sweeps)
 		else if (spec && std::strncmp(spec, "levelnowait=", 12) == 0)
 			set_syncfree_nowait(spec[12] - '0');  // measurements only: wrong results
+		else if (spec && std::strncmp(spec, "factorprobe=", 12) == 0)
+			set_factor_probe(spec[12] - '0');
+#else
+		else if (spec && (std::strncmp(spec, "gatherprobe=", 12) == 0 || std::strncmp(spec, "levelnowait=", 12) == 0 ||
+		                  std::strncmp(spec, "factorprobe=", 12) == 0))
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "this tuning string selects a timing experiment with WRONG results: it exists in the "
+			                              "probes build only (make -C blasted_amd/csrc probes; BLASTED_HIP_PROBES=1)");
+#endif
 		else if (spec && std::strncmp(spec, "levelfast=", 10) == 0)
 			set_level_fast(spec[10] - '0');  // (2: tests -- behave as if the polling launch had given up)
 		else if (spec && std::strncmp(spec, "levelserial=", 12) == 0)
@@ -2384,8 +2403,6 @@ int blasted_hip_set_tuning(const char *spec)
 			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
 		else if (spec && std::strncmp(spec, "factorfuse=", 11) == 0)
 			g_factor_fuse_init = spec[11] - '0';
-		else if (spec && std::strncmp(spec, "factorprobe=", 12) == 0)
-			set_factor_probe(spec[12] - '0');
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)
 			g_factor1_plan = spec[12] != '0';
 		else if (spec && std::strncmp(spec, "scalarstage=", 12) == 0)

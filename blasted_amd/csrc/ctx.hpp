@@ -57,6 +57,16 @@ struct Pattern {
 	const int *browptr = nullptr, *bcolind = nullptr, *diagind = nullptr;
 };
 
+// Measurement variants that give WRONG results on purpose (timing experiments that take a kernel apart) exist only in
+// the probes build of these sources (make probes -> libblasted_hip_probes.so, -DBHIP_PROBES; tools/probes/): in the
+// product library BHIP_PROBE(x) is the constant 0, the tuning strings that select them are turned down, and the extra
+// kernel instantiations are not built.
+#ifdef BHIP_PROBES
+#define BHIP_PROBE(x) (x)
+#else
+#define BHIP_PROBE(x) 0
+#endif
+
 struct SweepArgs {
 	Pattern pat;
 	const double *vals;     // block values the sweep multiplies with

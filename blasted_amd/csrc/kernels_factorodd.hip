@@ -175,6 +175,7 @@ static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipSt
 		return;
 	if (a.pat.bs == 5) {
 		const unsigned grid = (unsigned)((n + 15) / 16);
+#ifdef BHIP_PROBES
 		if (g_factor_probe == 1)
 			hipLaunchKernelGGL((factorodd_kernel<5, 1>), dim3(grid), dim3(256), 0, s, a, dinv);
 		else if (g_factor_probe == 2)
@@ -186,6 +187,7 @@ static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipSt
 		else if (g_factor_probe == 5)
 			hipLaunchKernelGGL((factorodd_kernel<5, 5>), dim3(grid), dim3(256), 0, s, a, dinv);
 		else
+#endif
 			hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, dinv);
 	} else {
 		const unsigned grid = (unsigned)((n + 7) / 8);

@@ -956,7 +956,7 @@ void launch_syncfree_fill(double *x, long n, hipStream_t s)
 	if (n <= 0)
 		return;
 	hipLaunchKernelGGL(sf_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-	                   reinterpret_cast<unsigned long long *>(x), n, g_sf_nowait ? 0ull : SF_PENDING);
+	                   reinterpret_cast<unsigned long long *>(x), n, BHIP_PROBE(g_sf_nowait) ? 0ull : SF_PENDING);
 }
 
 void set_syncfree_nowait(int on)

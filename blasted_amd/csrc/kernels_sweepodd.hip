@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 				if (!((DIAG_RIDES && isdiag) || (PART == PART_OFFDIAG && isdiag))) {
 					const int cidx = jj - jlo;
 					int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-					if (a.probe)
+					if (BHIP_PROBE(a.probe) == 1)
 						col = r0 + q.lr;  // (timing experiment: no gather, the row's own segment)
 					q.xv[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
 				}
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 						           : load16u(vbase + ((unsigned)(jj - jlo) * (unsigned)BLKBYTES + boff));
 						const int cidx = jj - jlo;
 						int col = (cidx < CAP) ? s_col[cidx] : a.pat.bcolind[jj];
-						if (a.probe)
+						if (BHIP_PROBE(a.probe) == 1)
 							col = r0 + q.lr;
 						x4[k] = load16u(xbase + ((unsigned)col * (unsigned)ROWBYTES + 8u * (unsigned)cx));
 					}

@@ -506,11 +506,11 @@ __global__ __launch_bounds__(256) void sweepw_kernel(const SweepArgs a)
 				if (SC) {
 					sc_store(dst, o0);
 					sc_store(dst + 8, o1);
-				} else if (IW && a.probe == 2) {
+				} else if (IW && BHIP_PROBE(a.probe) == 2) {
 					// (timing experiment, wrong results: only one row in 64 is stored)
 					if (lrow[u] % 64 == 0)
 						*reinterpret_cast<double2_t *>(dst) = o2;
-				} else if (IW && a.probe == 3)
+				} else if (IW && BHIP_PROBE(a.probe) == 3)
 					__builtin_nontemporal_store(o2, reinterpret_cast<double2_t *>(dst));
 				else
 					*reinterpret_cast<double2_t *>(dst) = o2;

@@ -163,6 +163,11 @@ public:
 	/// How THIS operator applies its asynchronous sweeps (ilu0, sgs): BLASTED_HIP_ASYNC, BLASTED_HIP_DETERMINISTIC or
 	/// BLASTED_HIP_LEVEL; a negative value (the default) follows the process-wide choice (detail::set_sweep_mode,
 	/// BLASTED_HIP_SWEEP_MODE).  Not in the reference; the PCSHELL glue sets it per KSP tree.
+	/// HBM this operator holds now (pattern / value mirrors, factor, derived copies, vectors; 0 before compute()), and
+	/// the device it was created on (ranks of a node share its GPUs round-robin: HipOperator::default_device).  Not in
+	/// the reference.
+	long deviceBytes() const;
+	int deviceIndex() const { return detail::HipOperator::default_device(); }
 	void setSweepMode(const int mode) { sweepmode_ = mode; }
 	int sweepMode() const { return sweepmode_ >= 0 ? sweepmode_ : detail::HipOperator::sweep_mode(); }
 

@@ -248,6 +248,16 @@ SRPreconditioner<scalar, index>::~SRPreconditioner()
 }
 
 template <typename scalar, typename index>
+long SRPreconditioner<scalar, index>::deviceBytes() const
+{
+	if (!op)
+		return 0;
+	long out[4] = {0, 0, 0, 0};
+	HipOperator::check(blasted_hip_memory_stats(op->get(), out));
+	return out[0];
+}
+
+template <typename scalar, typename index>
 void SRPreconditioner<scalar, index>::apply_at(const scalar *const, scalar *const, const int) const
 {
 	throw std::runtime_error("apply on device vectors is not provided by this operator");

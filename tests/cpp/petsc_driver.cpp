@@ -24,10 +24,13 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "blasted_petsc.h"
 #include "coomatrix.hpp"
+#include "solverops_base.hpp"
 
 using namespace blasted;
 
@@ -291,6 +294,17 @@ int main(int argc, char **argv)
 					l2 += (x[q] - ans[q]) * (x[q] - ans[q]);
 				std::printf("solve_error_l2 = %.6e\n", std::sqrt(l2));
 			}
+		}
+
+		// ---- where the operator lives (several ranks may share one GPU: one independent operator each)
+		if (bctx.size > 0 && bctx.ctxlist->bprec) {
+			const SRPreconditioner<double, int> *const prec = reinterpret_cast<const SRPreconditioner<double, int> *>(bctx.ctxlist->bprec);
+			std::printf("hip_device = %d\noperator_device_bytes = %ld\n", prec->deviceIndex(), prec->deviceBytes());
+		}
+		// --hold_s S: stay alive with the operator in HBM (tests that run several ranks on one GPU at the same time)
+		if (kv.count("--hold_s")) {
+			std::fflush(stdout);
+			std::this_thread::sleep_for(std::chrono::milliseconds((long)(1000 * std::atof(kv["--hold_s"].c_str()))));
 		}
 
 		// ---- timers, names, info list, teardown

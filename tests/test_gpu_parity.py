@@ -605,6 +605,20 @@ def test_fused_initialisation_builds_the_same_factor(golden, case):
                 dist[k, sweeps] = rel(f, exact)
             p.ilu0_factorize(90, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
             assert rel(p.get_iluvals(), exact) < TOL_EXACT
+        # the fused first sweep reads a row's own lower blocks back from the FACTOR storage right after other
+        # lanes of the wave stored them.  A stale read would return what the storage held before -- so poison it: the
+        # factor of a DIFFERENT matrix on the same pattern (values scaled row by row), then the fused build of the
+        # original one must come out as it did on clean storage.
+        rng = np.random.default_rng(3)
+        other = m["vals"].reshape(m["nnzb"], -1) * rng.uniform(0.5, 2.0, size=(m["nnzb"], 1))
+        for sweeps in (1, 2):
+            p.set_values(np.ascontiguousarray(other.reshape(-1)))
+            p.ilu0_factorize(5, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+            p.set_values(m["vals"])
+            p.ilu0_factorize(sweeps, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
+            f = p.get_iluvals()
+            assert np.all(np.isfinite(f))
+            assert rel(f, exact) < 4 * dist["0", sweeps] + 1e-13, (sweeps, rel(f, exact), dist)
     finally:
         capi.set_tuning("factorfuse=1")
         p.close()
@@ -639,7 +653,44 @@ def test_compact_copies_are_made_lazily(golden):
             p.sgs_apply(r, 2, mode=capi.JACOBI_SYNC)
         assert p.memory_stats()["derived_copies"] >= c0
     finally:
-        capi.set_tuning("compactafter=0")
+        capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))  # what it was (conftest.py)
+        p.close()
+
+
+@pytest.mark.parametrize("case,threshold", [("poisson16_csr", 4), ("poisson16_bs4", 16), ("poisson12_bs5", 8),
+                                            ("poisson9_bs8", 8), ("random_bs5", 8)])
+def test_product_default_makes_the_copies_inside_one_solve(golden, case, threshold):
+    """the SHIPPED policy (compactafter = -1: by block size -- 4 applications for scalar rows, 16 at bs = 4,
+    8 otherwise) is crossed inside one sequence of applications, as a solve does: the sweeps read the factor in place,
+    then switch kernels and data layout once the threshold-th application has come -- same bits before and after
+    (synchronous sweeps), the oracle's result throughout, and the asynchronous sweeps keep converging to the exact solves
+    across the switch."""
+    m = matrices(golden)[case]()
+    r = W.rhs_vector(m["nbrows"] * m["bs"])
+    p = make_prec(m)
+    capi.set_tuning("compactafter=-1")
+    try:
+        p.ilu0_factorize(3, mode=capi.JACOBI_SYNC)
+        gf = p.get_iluvals()
+        want = O.ilu0_apply(m, gf, r, 2, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)
+        copies, first = [], None
+        for k in range(threshold + 3):
+            copies.append(p.memory_stats()["derived_copies"])
+            z = p.ilu0_apply(r, 2, mode=capi.JACOBI_SYNC)
+            assert rel(z, want) < TOL_SYNC
+            first = z if first is None else first
+            assert np.array_equal(z, first)
+        assert copies[:threshold + 1] == [0] * (threshold + 1) and copies[threshold + 1:] == [2, 2]
+        # a new factorisation starts the count again; the asynchronous sweeps across the threshold
+        p.ilu0_factorize(-1)
+        exact = O.ilu0_apply(m, p.get_iluvals(), r, 1, mode=O.GS_SERIAL)
+        nlev = int(W.dependency_levels(m).max()) + 1
+        for k in range(threshold + 2):
+            z = p.ilu0_apply(r, nlev + 2, mode=capi.ASYNC)
+            assert rel(z, exact) < TOL_EXACT, k
+        assert p.memory_stats()["derived_copies"] == 2
+    finally:
+        capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))
         p.close()
 
 

@@ -343,3 +343,34 @@ def test_pcshell_rejects_bad_options(tmp_path):
     out = subprocess.run([DRIVER, "--mat_file", PMAT, "--", "-pc_type", "bjacobi", "-sub_pc_type", "none",
                           "-blasted_pc_type", "jacobi"], capture_output=True, text=True, timeout=120)
     assert "blasted_contexts = 0" in out.stdout and out.returncode != 0
+
+
+def test_two_ranks_share_one_gpu(tmp_path):
+    """VERDICT r03 item 8 (reference: one subdomain per rank, src/blasted_petsc.cpp:604-606; its own tests run
+    `mpirun -n 3/4`, tests/CMakeLists.txt:213-220): two PCSHELL driver processes at the same time, launched as an MPI
+    launcher would (OMPI_COMM_WORLD_LOCAL_RANK = 0 / 1).  On a one-GPU box both ranks map to device 0 (local rank modulo
+    the device count): each builds its own operator there -- independent contexts, each holding its own bytes of HBM --
+    and both match the oracle while the other one is alive."""
+    m = matrix("baij")
+    r = W.rhs_vector(m["nbrows"] * 4)
+    opts = ["-blasted_pc_type", "ilu0", "-blasted_async_sweeps", "3,3"] + ASYNC_OPTS
+    f = O.ilu0_factorize(m, None, 3, mode=O.JACOBI_SYNC, init=O.INIT_F_ORIGINAL)["iluvals"]
+    want = O.ilu0_apply(m, f, r, 3, mode=O.JACOBI_SYNC, init=O.INIT_A_ZERO)
+    procs = []
+    for rank in (0, 1):
+        out = str(tmp_path / ("rank%d" % rank))
+        cmd = [DRIVER, "--mat_file", PMAT, "--mat_type", "baij", "--vec_type", "seq", "--out", out, "--hold_s", "3",
+               "--", "-pc_type", "bjacobi", "-sub_pc_type", "shell"] + opts
+        e = {k: v for k, v in os.environ.items() if k not in ("BLASTED_HIP_DEVICE", "BLASTED_HIP_SWEEP_MODE", "BLASTED_HIP_EXACT_APPLY")}
+        e.update(SYNC, OMPI_COMM_WORLD_LOCAL_RANK=str(rank), OMPI_COMM_WORLD_RANK=str(rank), OMPI_COMM_WORLD_SIZE="2")
+        procs.append((out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)))
+    import torch
+    ndev = torch.cuda.device_count()
+    for rank, (out, pr) in enumerate(procs):
+        so, se = pr.communicate(timeout=300)
+        assert pr.returncode == 0, so[-3000:] + se[-2000:]
+        rep = dict(line.split(" = ", 1) for line in so.splitlines() if " = " in line)
+        assert rep["done"] == "1" and rep["blasted_contexts"] == "1"
+        assert int(rep["hip_device"]) == rank % ndev          # one GPU: both on device 0
+        assert int(rep["operator_device_bytes"]) > m["nnzb"] * 16 * 8    # its own factor (and more) in HBM
+        assert rel(np.fromfile(out + "_z.bin", np.float64), want) < 1e-12

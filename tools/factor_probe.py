@@ -2,9 +2,11 @@
 """Where the bs=5 factorisation sweep's time goes (config 4, unstructured): the sweep as it is, without the LDS tiles
 of the block products (factorprobe=1) and without the operand loads of the pairs (factorprobe=2) -- the probes give
 WRONG factors, only their time is of interest.  usage: factor_probe.py"""
+import os
 import sys
 import time
 
+os.environ.setdefault("BLASTED_HIP_PROBES", "1")  # the timing experiments exist in the probes build only (make -C blasted_amd/csrc probes)
 import torch
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BLASTED_HIP_PROBES=1  # gatherprobe exists in the probes build only (make -C blasted_amd/csrc probes)
 # Config 4 (unstructured bs=5): where the 1.4x traffic of the sweeps comes from.
 # Same-process A/B timings of the block-stream policy and of the no-gather probe, then rocprofv3 counter passes
 # (never combined with a trace) of bench.py --config 4 for the default, nt1 and the probe.
