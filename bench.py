@@ -520,14 +520,16 @@ def live_traffic(argv, op, budget_s=330.0):
         if skip:
             skip = False
             continue
-        if a in ("--steps", "--warmup", "--live-traffic"):
+        if a in ("--steps", "--warmup", "--live-traffic", "--placement"):
             skip = True
             continue
-        if a.startswith(("--steps=", "--warmup=", "--live-traffic=")):
+        if a.startswith(("--steps=", "--warmup=", "--live-traffic=", "--placement=")):
             continue
         child.append(a)
     cmd_tail = [sys.executable, os.path.abspath(__file__)] + child + [
-        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--live-traffic", "off"]
+        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--live-traffic", "off",
+        # (the bytes a kernel moves do not depend on where its buffers lie: no placement search in the counter passes)
+        "--placement", "0", "--no-product-default"]
     env = dict(os.environ, TMPDIR="/tmp", BLASTED_BENCH_PMC_CHILD="1")
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -833,6 +833,7 @@ static void place_ytemp(blasted_hip_prec p, const double *dr, const double *dz)
 	p->ytemp = moved;
 }
 
+static int g_small_apply = 1;  // tuning "smallapply=0": see blasted_hip_ilu0_apply
 static int g_level_perm = 1;  // tuning: exact ILU solves keep their iterate level-ordered (bs 4/8 column-major)
 
 // tuning "applynone=1" (tests: the reference's "-initialization exact" fixed-point cases of the triangular sweeps,
@@ -863,17 +864,10 @@ static int exact_pass_permuted(blasted_hip_prec p, SweepArgs a, bool upper, doub
 	if (upper && !p->y_in_level_order)
 		return 0;
 	const long n = p->n();
-	double *&mine = upper ? p->zperm : p->yperm;
-	if (!mine) {
-		// the level-ordered iterate this pass WRITES: not in the address class of the triangle copy it streams (placed_alloc)
-		PlaceHint h;
-		h.avoid = view.vals;
-		h.ref_bytes = sizeof(double) * (size_t)n;
-		if (trace_placement())
-			std::fprintf(stderr, "[blasted_hip] level-ordered %s iterate:\n", upper ? "z" : "y");
-		mine = dev_alloc_placed<double>((size_t)n, h, p->stream);
-	}
-	double *out = mine;
+	// (round 4: the level-ordered iterates placed out of the address class of the triangle copy the pass streams --
+	// placed_alloc -- changed nothing: 5.55 against 5.64 ms per exact application at 256^3 bs=4; these passes wait on
+	// dependencies, not on the memory system.  Plain allocations.)
+	double *out = upper ? ensure(p->zperm, n) : ensure(p->yperm, n);
 	launch_syncfree_fill(out, n, p->stream);
 	a.vals = view.vals;
 	a.xin = out;
@@ -1136,6 +1130,7 @@ int blasted_hip_destroy(blasted_hip_prec p)
 		dev_free(p->ytemp);
 		dev_free(p->yperm);
 		dev_free(p->zperm);
+		dev_free(p->zeros);
 		dev_free(p->dblocks);
 		for (int i = 0; i < 3; i++) {
 			dev_free(p->tmp[i]);
@@ -1536,7 +1531,20 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 
 		// y := 0 (both init types), src/solverops_ilu0.cpp:83-94.  The prologue z := S r is fused: the
 		// lower sweeps read r (times scale) directly as their right-hand side.
-		if (!skip_first && !keep_iterates) {
+		// A small (cache-resident) problem is launch-bound -- 64^3 scalar: eight launches 5.7 us apart for 46 us of
+		// kernels -- so its two fills go: the first sweep of each triangle READS an operator-owned vector of zeros that
+		// nobody ever writes (in = zeros, out = the iterate), the sweeps after it run in place.  With every row of such a
+		// problem in flight at once the first in-place sweep from a zeroed iterate was a Jacobi sweep from zero anyway.
+		// (Round 4; the whole application as ONE cooperative launch with grid barriers was built, verified and removed: its
+		// iterate needs agent-scope accesses, which go past the L2s -- 270 us per application against 47:
+		// tools/probes/removed/kernels_fused1.hip.txt.)  tuning "smallapply=0": the fills as before.
+		const bool small_apply = g_small_apply && mode == BLASTED_HIP_ASYNC && napplysweeps > 0 && !keep_iterates && n > 0 &&
+		                         (long)p->pat.nnzb * (8L * p->pat.bs * p->pat.bs + 4) + n * 32 < (96L << 20);
+		if (small_apply && !p->zeros) {
+			p->zeros = dev_alloc<double>((size_t)n);
+			BHIP_CHECK(hipMemsetAsync(p->zeros, 0, nbytes, p->stream));
+		}
+		if (!skip_first && !keep_iterates && !small_apply) {
 			Phase ph(p, 2);
 			BHIP_CHECK(hipMemsetAsync(p->ytemp, 0, nbytes, p->stream));
 			ph.launches = 1;
@@ -1578,8 +1586,12 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 				y = p->ytemp;
 			} else
 				y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, y1, napplysweeps - 1, mode, 0);
-		} else
-			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, nullptr, napplysweeps, mode, 0);
+		} else if (small_apply && !p->scaled && napplysweeps >= 2)
+			// (from y0 = 0 the first lower sweep gives y1 = r exactly -- the skipped products are with zeros -- so the
+			// second one can read r as its iterate: one launch less)
+			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, dr, napplysweeps - 1, mode, 0);
+		else
+			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, small_apply ? p->zeros : nullptr, napplysweeps, mode, 0);
 		double *yfree = (y == p->ytemp) ? yother : p->ytemp;  // Jacobi mode: the non-final y buffer
 
 		// z := y or z := 0, then upper sweeps, src/solverops_ilu0.cpp:110-141
@@ -1613,6 +1625,8 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 			const double *first_in = nullptr;
 			if (apply_init == BLASTED_HIP_INIT_A_JACOBI)
 				first_in = y;  // z0 = y: the first sweep gathers from y, no copy needed
+			else if (small_apply)
+				first_in = p->zeros;  // z0 = 0 without a fill (see above)
 			else if (!keep_iterates) {
 				Phase ph(p, 2);
 				BHIP_CHECK(hipMemsetAsync(dz, 0, nbytes, p->stream));
@@ -2362,6 +2376,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_compact = spec[8] != '0';
 		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
 			g_compact_after = std::atol(spec + 13);
+		else if (spec && std::strncmp(spec, "smallapply=", 11) == 0)
+			g_small_apply = spec[11] != '0';
 		else if (spec && std::strncmp(spec, "placement=", 10) == 0)
 			g_placement = spec[10] == '0' ? 0 : (spec[10] == '2' ? 2 : 1);
 		else if (spec && std::strncmp(spec, "applynone=", 10) == 0)

@@ -313,6 +313,8 @@ struct blasted_hip_prec_s {
 
 	bhip::Timing timing;
 
+	double *zeros = nullptr;  // n zeros, never written: the iterate the first sweep of a small application reads (capi.hip)
+
 	long bytes_owned = 0, bytes_peak = 0;  // device memory this operator holds (tracked_malloc)
 
 	// class-aware placement (capi.hip, placed_alloc): what the next derived copy should avoid / share its address

@@ -1340,3 +1340,47 @@ def test_async_relaxation_convergence_and_bound(golden):
     assert res["gs"][2] < 1e-5 and res["gs"][1] < 200          # convergence
     assert res["sgs"][2] < 1e-5 and res["sgs"][1] < res["jacobi"][1]   # upper_bound_its
     p.close()
+
+
+# ---------------------------------------------------------------------------- small problems: no fills
+
+@pytest.mark.parametrize("case", ["poisson16_csr", "msc_csr", "2dcyl1_csr", "random_csr", "poisson16_bs4", "poisson12_bs5", "2dcyl1_bs4_col"])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_small_application_without_fills_converges_to_exact(golden, case, usescale):
+    """VERDICT r03 item 6 (the part that was kept): a cache-resident problem's asynchronous ILU(0) application runs as
+    2 s launches instead of 2 s + 2 -- the first sweep of each triangle reads an operator-owned vector of zeros instead of
+    a freshly zeroed iterate -- and reaches the oracle's exact solves like the form with the fills (`smallapply=0`), from
+    both initial guesses, with and without scaling, for device and host vectors."""
+    import torch
+    m = matrices(golden)[case]()
+    n = m["nbrows"] * m["bs"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.ilu0_factorize(-1, usescale=usescale)
+    f = p.get_iluvals()
+    scale = p.get_scale() if usescale else None
+    exact, ey = O.ilu0_apply(m, f, r, 1, mode=O.GS_SERIAL, scale=scale, return_y=True)
+    nlev = int(W.dependency_levels(m).max()) + 1
+    s = nlev + 2
+    rd = torch.from_numpy(r).cuda()
+    try:
+        for small in ("1", "0"):
+            capi.set_tuning("smallapply=" + small)
+            for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
+                z = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")   # whatever the caller's z held
+                p.set_timing(True)
+                p.get_timing()
+                p.ilu0_apply(rd, s, init=init, mode=capi.ASYNC, out=z)
+                t = p.get_timing()
+                p.set_timing(False)
+                assert rel(z.cpu().numpy(), exact) < TOL_EXACT, (small, init)
+                assert rel(p.get_ytemp(), ey) < TOL_EXACT
+                launches = t["lower_launches"] + t["upper_launches"] + t["other_launches"]
+                fills = (0 if small == "1" else 1 + (init == capi.INIT_A_ZERO)) + (1 if usescale else 0)  # (+ z := S z)
+                # (unscaled: the first lower sweep from zero is y1 = r, so the second one reads r -- one launch less)
+                assert launches == 2 * s + fills - (1 if small == "1" and not usescale else 0)
+            zh = p.ilu0_apply(r, s, mode=capi.ASYNC)            # host vectors
+            assert rel(zh, exact) < TOL_EXACT
+    finally:
+        capi.set_tuning("smallapply=1")
+        p.close()
