@@ -187,13 +187,17 @@ static double probe_ms(const void *rd, size_t rd_bytes, void *wr, size_t wr_byte
 	return best;
 }
 
+// What a buffer's pieces should be: MUST not share the class of `avoid` / `avoid2` (the 10 % constraint: the vector the
+// sweep writes) and SHOULD share the class of `prefer` (the 2-3 % one: the other streams the sweep reads).  `same` is a
+// must-share (the probes' and place_ytemp's use).
 struct PlaceHint {
-	const void *avoid = nullptr, *avoid2 = nullptr, *same = nullptr;
+	const void *avoid = nullptr, *avoid2 = nullptr, *same = nullptr, *prefer = nullptr;
 	size_t ref_bytes = 0;  // length of those vectors
-	bool any() const { return avoid || avoid2 || same; }
+	bool any() const { return avoid || avoid2 || same || prefer; }
 };
 
-// Does `piece` (device memory; its contents are rewritten unchanged) satisfy the hint?  +1 yes, -1 no, 0 cannot tell.
+// Does `piece` (device memory; its contents are rewritten unchanged) satisfy the hint?  +2: musts and the preference,
+// +1: the musts only, -1: a must is violated, 0: cannot tell (too small to time).
 // The probe is timed once with its writes inside the piece itself (the "same class" time) and once per reference vector.
 static int class_fits(void *piece, size_t piece_bytes, const PlaceHint &h, double *sink, hipStream_t s)
 {
@@ -209,19 +213,20 @@ static int class_fits(void *piece, size_t piece_bytes, const PlaceHint &h, doubl
 	const double thr = 0.955;
 	static const bool trace = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
 	const double t_self = probe_ms(piece, rd, static_cast<char *>(piece) + rd - wr, wr, reps, sink, s);
-	int fits = +1;
-	const void *refs[3] = {h.same, h.avoid, h.avoid2};
-	for (int k = 0; k < 3 && fits > 0; k++) {
+	int fits = +2;
+	const void *refs[4] = {h.same, h.avoid, h.avoid2, h.prefer};
+	for (int k = 0; k < 4 && fits > 0; k++) {
 		if (!refs[k])
 			continue;
 		const double t_ref = probe_ms(piece, rd, const_cast<void *>(refs[k]), wr, reps, sink, s);
 		const bool other_class = t_ref < thr * t_self;
+		const bool want_same = k == 0 || k == 3;
 		if (trace)
-			std::fprintf(stderr, "[blasted_hip] class probe: piece %p (%zu MiB) against %p: self %.4f ms, ref %.4f ms, ratio %.3f -> %s (wanted: %s)\n",
+			std::fprintf(stderr, "[blasted_hip] class probe: piece %p (%zu MiB) against %p: self %.4f ms, ref %.4f ms, ratio %.3f -> %s (%s: %s)\n",
 			             piece, piece_bytes >> 20, refs[k], t_self, t_ref, t_ref / t_self, other_class ? "another class" : "same class",
-			             k == 0 ? "same" : "another");
-		if (other_class != (k != 0))
-			fits = -1;
+			             k == 3 ? "preferred" : "must be", want_same ? "same" : "another");
+		if (other_class == want_same)
+			fits = k == 3 ? +1 : -1;
 	}
 	return fits;
 }
@@ -273,7 +278,7 @@ static double now_ms()
 // caller allocates plainly)
 static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 {
-	const void *ref = h.same ? h.same : (h.avoid ? h.avoid : h.avoid2);
+	const void *ref = h.same ? h.same : (h.avoid ? h.avoid : (h.avoid2 ? h.avoid2 : h.prefer));
 	if (!g_placement || !ref || bytes < ((size_t)256 << 20) || h.ref_bytes < ((size_t)16 << 20))
 		return nullptr;
 	static const bool trace = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
@@ -319,9 +324,39 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	double *sink = nullptr;
 	bool ok = hipMalloc(&sink, sizeof(double)) == hipSuccess;
 	int misses = 0;           // consecutive pieces of the wrong class
-	long unchecked = 0, turned = 0;
+	long unchecked = 0, turned = 0, second_best = 0;
+	// pieces that meet the musts but not the preference: held, and used for the slots that are still empty when the
+	// search for better ones ends (full-size pieces only: the last, shorter slot takes what comes)
+	std::vector<hipMemGenericAllocationHandle_t> fallback;
+	size_t searched_since_enough = 0;
 	for (size_t at = 0; ok && at < total;) {
 		const size_t sz = total - at < piece ? total - at : piece;
+		const size_t slots_left = (total - at + piece - 1) / piece;
+		if (!fallback.empty() && sz == piece) {
+			// enough second-best pieces for every empty slot, and 32 GiB more looked at since: settle for them
+			const bool enough = fallback.size() >= slots_left && searched_since_enough >= ((size_t)32 << 30);
+			const bool out_of_budget = held_bytes + sz > budget || tries >= max_tries || now_ms() - t_start >= budget_ms;
+			if (enough || out_of_budget) {
+				hipMemGenericAllocationHandle_t hf = fallback.back();
+				fallback.pop_back();
+				char *where = static_cast<char *>(va) + at;
+				hipError_t e = hipMemMap(where, sz, 0, hf, 0);
+				if (e == hipSuccess)
+					e = hipMemSetAccess(where, sz, &acc, 1);
+				if (e != hipSuccess) {
+					(void)hipMemRelease(hf);
+					ok = false;
+					break;
+				}
+				(void)hipMemRelease(hf);
+				held_bytes -= sz;
+				mapped.emplace_back(at, sz);
+				g_place_stats.pieces++;
+				second_best++;
+				at += sz;
+				continue;
+			}
+		}
 		// after two misses in a row: step over a larger stretch of the driver's free memory without looking at it
 		if (misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget && now_ms() - t_start < budget_ms) {
 			size_t sp = (size_t)1 << (30 + (misses < 6 ? misses - 1 : 5));  // 2, 4, 8, 16, 32 GiB
@@ -331,6 +366,8 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 			if (hipMemCreate(&hs, sp, &prop, 0) == hipSuccess) {
 				held.push_back(hs);
 				held_bytes += sp;
+				if (fallback.size() >= slots_left)
+					searched_since_enough += sp;
 			} else
 				(void)hipGetLastError();
 		}
@@ -364,12 +401,20 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 			} else
 				(void)hipGetLastError();
 		}
+		if (rel == 1 && sz == piece) {  // the musts only: keep it in reserve, look on
+			fallback.push_back(hd);
+			held_bytes += sz;
+			misses++;
+			continue;
+		}
 		if (rel < 0) {
 			held.push_back(hd);
 			held_bytes += sz;
 			misses++;
 			turned++;
 			g_place_stats.rejected++;
+			if (fallback.size() >= slots_left)
+				searched_since_enough += sz;
 			continue;
 		}
 		e = hipMemMap(where, sz, 0, hd, 0);
@@ -394,6 +439,8 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	}
 	for (auto hd : held)
 		(void)hipMemRelease(hd);
+	for (auto hd : fallback)
+		(void)hipMemRelease(hd);
 	if (sink)
 		(void)hipFree(sink);
 	if (!ok) {
@@ -405,9 +452,10 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	}
 	trace_alloc(va, bytes);
 	if (trace)
-		std::fprintf(stderr, "[blasted_hip] placed %zu MiB at %p (%s %p): %zu pieces, %ld turned down, %ld kept unchecked, %zu MiB "
-		             "held back for the search, %.1f ms\n", total >> 20, va, h.same ? "class of" : "not the class of", ref,
-		             mapped.size(), turned, unchecked, held_bytes >> 20, now_ms() - t_start);
+		std::fprintf(stderr, "[blasted_hip] placed %zu MiB at %p (%s %p): %zu pieces (%ld of them second best: the musts without the "
+		             "preference), %ld turned down, %ld kept unchecked, %zu MiB held back for the search, %.1f ms\n", total >> 20, va,
+		             h.same ? "class of" : (h.prefer ? "preferably the class of" : "not the class of"), h.prefer ? h.prefer : ref,
+		             mapped.size(), second_best, turned, unchecked, held_bytes >> 20, now_ms() - t_start);
 	AllocRegistry &r = alloc_registry();
 	std::lock_guard<std::mutex> lk(r.mu);
 	AllocRegistry::Rec rec;
@@ -687,7 +735,7 @@ static void refresh_copy(blasted_hip_prec p, const LevelSchedule &st, const doub
 	if (!mine) {
 		PlaceHint hint;
 		hint.avoid = p->place_avoid;
-		hint.same = p->place_same;
+		hint.prefer = p->place_same;  // (a preference: a piece that only stays out of `avoid`'s class is second best)
 		hint.ref_bytes = p->place_ref_bytes;
 		if (trace_placement())
 			std::fprintf(stderr, "[blasted_hip] %s triangle copy, %s order:\n", upper ? "upper" : "lower", &st == &p->natstore ? "natural" : "level");
@@ -1557,17 +1605,15 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->fac_applies, p->fac_nat);
 		if (compact) {
-			// thorough ("placement=2"): the lower copy in r's class, ytemp in neither r's nor z's, the upper copy in ytemp's
-			// (place_ytemp); default: only what costs 10 % when it goes wrong -- the lower copy not in ytemp's class, the
-			// upper copy not in z's (two of three classes will do: a search that holds back little finds them)
-			if (g_placement >= 2)
-				set_place_hint(p, nullptr, dr);
-			else
-				set_place_hint(p, p->ytemp, nullptr);
+			// Musts (10 % each when they go wrong): the lower copy not in ytemp's class, the upper copy not in z's -- two of
+			// three classes will do, a search that holds back little finds them: the default.  Thorough ("placement=2") adds
+			// the preferences: ytemp moved out of r's and z's classes first (place_ytemp), then the lower copy preferably in
+			// r's class and the upper copy preferably in ytemp's; pieces that only meet the must are second best.
+			if (g_placement >= 2 && !p->fac_nat.l)
+				place_ytemp(p, dr, dz);
+			set_place_hint(p, p->ytemp, g_placement >= 2 ? dr : nullptr);
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
-			if (g_placement >= 2)
-				place_ytemp(p, dr, dz);
 		}
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y;
@@ -1601,10 +1647,7 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rhs = y;
 		a.descending = 1;
 		if (compact) {
-			if (g_placement >= 2)
-				set_place_hint(p, nullptr, p->ytemp);
-			else
-				set_place_hint(p, dz, nullptr);
+			set_place_hint(p, dz, g_placement >= 2 ? p->ytemp : nullptr);
 			const bool fresh = !p->fac_nat.u;
 			compact_args(p, true, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);

@@ -152,6 +152,14 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 						lp = a.lowerp[kb + kk];
 						up = a.upperp[kb + kk];
 					}
+					// (lrow_fresh -- the fused first sweep of a build, in = the matrix, out = the factor: the row's own lower
+					// block l_ik is read back from `out`, where other lanes of THIS wave stored it a few instructions
+					// ago with plain stores.  That relies on in-wave memory ordering: a wave's vector-memory accesses to
+					// one address are performed in program order -- the stores above are issued before this load and the
+					// hardware returns the stored data (same wave, same address, same cache path; the compiler cannot
+					// reorder them: `out` is not restrict-qualified and the accesses may alias).  No other wave writes
+					// this row.  tests/test_gpu_parity.py::test_fused_initialisation_builds_the_same_factor runs the
+					// fused build on factor storage POISONED with another matrix's factor: a stale read would surface.)
 					lval = (a.lrow_fresh ? a.out : a.in)[(long)lp * 16 + offA];
 					uval = a.in[(long)up * 16 + offD];
 				}

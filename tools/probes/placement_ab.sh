@@ -6,7 +6,7 @@ echo "# bench.py --config 2 --steps 10 --warmup 3 in fresh processes: lower / up
 for i in $(seq 1 $N); do
   for pl in $VARS; do
     t0=$(date +%s.%N)
-    BLASTED_HIP_TRACE_PLACEMENT=1 BLASTED_HIP_PLACEMENT=$pl timeout -k 10 200 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --live-traffic off 2>$OUT.err | python -c "
+    BLASTED_HIP_TRACE_PLACEMENT=1 timeout -k 10 200 python bench.py --placement $pl --no-product-default --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --live-traffic off 2>$OUT.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; pl = d.get('placement', {})
 w = pl.get('where', {})

@@ -1,11 +1,11 @@
 #!/bin/bash
 # GPU box: the upper / lower sweep times of the headline configuration in N FRESH processes (every buffer
 # re-allocated by a new process each time): the process-to-process spread VERDICT r01 #6 asks about.
-# usage: tools/probes/placement_processes.sh <out.txt> [N=12]
+# usage: [PLACEMENT=0|1|2] tools/probes/placement_processes.sh <out.txt> [N=12]   (bench.py's own default is the thorough placement, 2)
 OUT=$1; N=${2:-12}
 echo "# bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline in $N fresh processes: lower / upper sweep ms, fraction of 8 TB/s of the upper sweep, sweeps/s" > $OUT
 for i in $(seq 1 $N); do
-  timeout -k 10 200 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  timeout -k 10 200 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-product-default --live-traffic off ${PLACEMENT:+--placement $PLACEMENT} 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('process %2d: lower %.3f ms  upper %.3f ms  frac %.3f  value %.1f' % ($i, r['lower_ms'], r['upper_ms'], r['frac'], d['value']))" >> $OUT || exit 1
