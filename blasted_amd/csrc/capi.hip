@@ -279,7 +279,7 @@ static double now_ms()
 static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 {
 	const void *ref = h.same ? h.same : (h.avoid ? h.avoid : (h.avoid2 ? h.avoid2 : h.prefer));
-	if (!g_placement || !ref || bytes < ((size_t)256 << 20) || h.ref_bytes < ((size_t)16 << 20))
+	if (!g_placement || !ref || bytes < ((size_t)64 << 20) || h.ref_bytes < ((size_t)16 << 20))
 		return nullptr;
 	static const bool trace = std::getenv("BLASTED_HIP_TRACE_PLACEMENT") != nullptr;
 	const double t_start = now_ms();
@@ -858,7 +858,7 @@ static void report_classes(blasted_hip_prec p, const double *dr, const double *d
 static void place_ytemp(blasted_hip_prec p, const double *dr, const double *dz)
 {
 	const size_t nbytes = sizeof(double) * (size_t)p->n();
-	if (!g_placement || p->ytemp_placed || !p->ytemp || nbytes < ((size_t)256 << 20))
+	if (!g_placement || p->ytemp_placed || !p->ytemp || nbytes < ((size_t)64 << 20))
 		return;
 	p->ytemp_placed = true;
 	PlaceHint h;
