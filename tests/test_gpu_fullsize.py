@@ -263,3 +263,45 @@ def test_scalar_many_rows_takes_the_wide_chunks():
         assert torch.equal(a, b)
     assert relmax(res["0"][0], torch_part_matvec(m, m["vals"], r, "all")) < 1e-13
     p.close()
+
+
+def test_class_aware_placement_changes_where_not_what():
+    """Round 4: the compact triangle copies of an operator large enough for it (copies of 64 MiB and more:
+    here Poisson 128^3 bs=4, 768 / 1018 MiB) are built from 1 GiB pieces that are checked, with a read-beside-write probe,
+    against the vectors the sweeps read and write.  Whatever the search does -- off, quick, thorough -- the synchronous
+    sweeps give the SAME BITS; the placement counters move; `placement_check` answers; and the operator's memory
+    accounting still adds up when it is destroyed and another one is made."""
+    import torch
+    dev = torch.device("cuda:0")
+    m = W.poisson3d_device(128, 4, dev, grid="uniform")
+    n = m["nbrows"] * 4
+    r = W.rhs_vector_device(n, dev)
+    results = {}
+    try:
+        for mode in ("0", "1", "2"):
+            capi.set_tuning("placement=" + mode)
+            before = capi.placement_stats()
+            p = capi.Prec(0)
+            p.set_matrix(m)
+            p.ilu0_factorize(-1)
+            z = torch.zeros_like(r)
+            p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC, out=z)
+            results[mode] = z.clone()
+            za = p.ilu0_apply(r, 3, mode=capi.ASYNC).clone()     # asynchronous sweeps on the same copies
+            assert torch.isfinite(za).all()
+            after = capi.placement_stats()
+            where = p.placement_check(r, z)
+            assert where["lower_pieces"] == 1 and where["upper_pieces"] == 1      # 768 MiB and 1018 MiB: one piece each
+            if mode == "0":
+                assert after["buffers"] == before["buffers"]
+            else:
+                assert after["buffers"] >= before["buffers"] + 2 and after["probes"] > before["probes"]
+                # the musts: whatever was checked is not in the class of the vector the sweep writes
+                if after["unchecked"] == before["unchecked"]:
+                    assert where["upper_in_z_class"] == 0 and where["lower_in_ytemp_class"] == 0
+            st = p.memory_stats()
+            assert st["bytes"] > 0 and st["derived_copies"] == 2
+            p.close()
+    finally:
+        capi.set_tuning("placement=1")
+    assert torch.equal(results["0"], results["1"]) and torch.equal(results["0"], results["2"])
