@@ -2558,9 +2558,9 @@ int blasted_hip_probe_place(blasted_hip_prec p, const char *what, void *where)
 		use_device(p);
 		BHIP_CHECK(hipStreamSynchronize(p->stream));
 		const std::string w = what ? what : "";
-		double *&buf = w == "ytemp" ? p->ytemp : (w == "ucopy" ? p->fac_nat.u : p->fac_nat.l);
-		if (w != "ytemp" && w != "ucopy" && w != "lcopy")
-			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_place: ytemp | ucopy | lcopy");
+		double *&buf = w == "ytemp" ? p->ytemp : (w == "ucopy" ? p->fac_nat.u : (w == "iluvals" ? p->iluvals : p->fac_nat.l));
+		if (w != "ytemp" && w != "ucopy" && w != "lcopy" && w != "iluvals")
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "probe_place: ytemp | ucopy | lcopy | iluvals");
 		{
 			AllocRegistry &r = alloc_registry();
 			bool mine;
@@ -2578,6 +2578,11 @@ int blasted_hip_probe_place(blasted_hip_prec p, const char *what, void *where)
 			p->fac_nat.valid_l = false;
 		if (w == "ytemp" && where)
 			BHIP_CHECK(hipMemset(where, 0, sizeof(double) * (size_t)p->n()));
+		if (w == "iluvals") {
+			p->fac_nat.invalidate();
+			p->fac_lvl.invalidate();
+			p->factored = false;
+		}
 	});
 }
 
