@@ -58,11 +58,17 @@ static size_t g_alloc_offset = [] {
 	return e ? (size_t)std::atol(e) & ~(size_t)255 : (size_t)0;
 }();
 
+static bool release_deferred();  // (class-aware placement, below: memory a search still holds back)
+
 hipError_t tracked_malloc(void **p, size_t bytes)
 {
 	const size_t off = bytes >= (64u << 20) ? g_alloc_offset : 0;
 	void *base = nullptr;
-	const hipError_t e = hipMalloc(&base, bytes + off);
+	hipError_t e = hipMalloc(&base, bytes + off);
+	if (e != hipSuccess && release_deferred()) {
+		(void)hipGetLastError();
+		e = hipMalloc(&base, bytes + off);
+	}
 	if (e != hipSuccess)
 		return e;
 	*p = static_cast<char *>(base) + off;
@@ -154,6 +160,25 @@ static int g_placement = [] {
 	const char *e = std::getenv("BLASTED_HIP_PLACEMENT");
 	return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
 }();
+
+// Pieces and spacers a search held back are handed back LATER -- at the end of the entry point that made the buffers --
+// not between one buffer's search and the next: the driver wipes released memory and makes the next allocation wait for
+// it, and inside one application three buffers are placed one after the other (6 s of waiting seen, for searches that
+// take 0.1 s when nothing is being wiped).
+static std::vector<hipMemGenericAllocationHandle_t> g_deferred_release;
+static std::mutex g_deferred_mu;  // (operators of different threads share the list)
+
+static bool release_deferred()  // true: there was something to release
+{
+	std::vector<hipMemGenericAllocationHandle_t> mine;
+	{
+		std::lock_guard<std::mutex> lk(g_deferred_mu);
+		mine.swap(g_deferred_release);
+	}
+	for (auto hd : mine)
+		(void)hipMemRelease(hd);
+	return !mine.empty();
+}
 
 struct PlaceStats {
 	long placed_buffers = 0, pieces = 0, rejected = 0, gave_up = 0, probes = 0;
@@ -373,6 +398,10 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 		}
 		hipMemGenericAllocationHandle_t hd;
 		hipError_t e = hipMemCreate(&hd, sz, &prop, 0);
+		if (e != hipSuccess && release_deferred()) {  // what earlier searches still hold may be what is missing
+			(void)hipGetLastError();
+			e = hipMemCreate(&hd, sz, &prop, 0);
+		}
 		if (e != hipSuccess) {
 			if (trace)
 				std::fprintf(stderr, "[blasted_hip] placed_alloc: hipMemCreate(%zu) failed: %s\n", sz, hipGetErrorString(e));
@@ -437,10 +466,11 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 		g_place_stats.pieces++;
 		at += sz;
 	}
-	for (auto hd : held)
-		(void)hipMemRelease(hd);
-	for (auto hd : fallback)
-		(void)hipMemRelease(hd);
+	{
+		std::lock_guard<std::mutex> lk(g_deferred_mu);
+		g_deferred_release.insert(g_deferred_release.end(), held.begin(), held.end());
+		g_deferred_release.insert(g_deferred_release.end(), fallback.begin(), fallback.end());
+	}
 	if (sink)
 		(void)hipFree(sink);
 	if (!ok) {
@@ -486,7 +516,11 @@ template <typename F>
 static int guarded(F &&f)
 {
 	struct OwnerReset {
-		~OwnerReset() { tl_owner = nullptr; }
+		~OwnerReset()
+		{
+			tl_owner = nullptr;
+			(void)release_deferred();  // what a placement search of this call held back goes back to the driver now
+		}
 	} reset;
 	try {
 		f();
