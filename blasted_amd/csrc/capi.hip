@@ -275,16 +275,20 @@ static double place_budget_ms(size_t bytes)
 
 // And what a search holds back it must hand back: the driver wipes released memory (about 30 ms per GiB on these
 // boxes) and the NEXT allocation of the process waits for that -- a search that had stepped over 200 GiB made the
-// allocation after it take 6 s (profiles/r04_placement_ab_unbounded_bytes.txt).  Default: at most 8 GiB.
+// allocation after it take 6 s (profiles/r04_placement_ab_unbounded_bytes.txt).  The release is therefore put off to the
+// end of the entry point (release_deferred): the searches themselves no longer wait, whoever allocates next in the
+// process does, once.  Default (quick) search: at most 32 GiB and a quarter of what is free.
 static size_t place_budget(size_t bytes)
 {
-	size_t want = g_placement >= 2 ? (size_t)256 << 30 : (size_t)8 << 30;
+	size_t want = g_placement >= 2 ? (size_t)256 << 30 : (size_t)32 << 30;
 	// never more than what is free now, less the buffer itself and a reserve for everybody else on the device
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
 		return 0;
 	const size_t reserve = bytes + total_b / 8;
-	const size_t room = free_b > reserve ? free_b - reserve : 0;
+	size_t room = free_b > reserve ? free_b - reserve : 0;
+	if (g_placement < 2 && room > free_b / 4)
+		room = free_b / 4;  // (other ranks may share the device: the default never holds back more than a quarter of what is free)
 	return want < room ? want : room;
 }
 
