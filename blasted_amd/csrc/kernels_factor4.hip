@@ -76,6 +76,9 @@ __device__ __forceinline__ double inverse_b_layout(const double v, const int k, 
 // 128^3 0.853 -> 0.922 ms, 256^3 6.86 -> 7.41 ms per sweep.  At bs=8 the same change is worth 27 %; here the sweep
 // already moves 36.6 GB in 6.9 ms = 5.3 TB/s of read+write traffic, near what a copy reaches on these boxes
 // (profiles/r01l_stream_ceiling.txt: 5.8-6.3 TB/s), so there is no latency left to hide and the lost waves cost.
+// Round 4, after request-ahead had paid in kernels_factorodd.hip (12-25 %): here, at the same eight waves and 62
+// registers, the operand blocks of pair k + 1 requested before the product of pair k cost 1.5 %, and the position of a
+// lower block's u_jj requested one block ahead 10 % (profiles/r04_factor4_pipe_ab.txt).  Not kept.
 __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 {
 	__shared__ int s_rp[F4_RCHUNK + 1];
