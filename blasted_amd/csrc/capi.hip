@@ -919,7 +919,7 @@ static void place_ytemp(blasted_hip_prec p, const double *dr, const double *dz)
 	p->ytemp = moved;
 }
 
-static int g_small_apply = 1;  // tuning "smallapply=0": see blasted_hip_ilu0_apply
+static int g_small_apply = 2;  // tuning "smallapply=0|1|2": see blasted_hip_ilu0_apply (1: without the fused first upper sweep)
 static int g_level_perm = 1;  // tuning: exact ILU solves keep their iterate level-ordered (bs 4/8 column-major)
 
 // tuning "applynone=1" (tests: the reference's "-initialization exact" fixed-point cases of the triangular sweeps,
@@ -1107,7 +1107,8 @@ static SweepArgs base_args(blasted_hip_prec p)
 // ASYNC: in place.  JACOBI_SYNC: ping-pong between x and `other`; first_in (optional) is read by the
 // first sweep instead of x.  Returns the buffer holding the final iterate (x or other).
 static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post, DSrc dsrc, double *x,
-                          double *other, const double *first_in, int nsweeps, int mode, int kind)
+                          double *other, const double *first_in, int nsweeps, int mode, int kind,
+                          double *z1_of_last = nullptr)
 {
 	Phase ph(p, kind);
 	if (nsweeps < 0 || mode == BLASTED_HIP_LEVEL) {
@@ -1133,6 +1134,7 @@ static double *run_sweeps(blasted_hip_prec p, SweepArgs a, Part part, Post post,
 			out = (s == 0 && first_in) ? x : (cur == x ? other : x);
 		a.xin = in;
 		a.xout = out;
+		a.z1out = (s == nsweeps - 1) ? z1_of_last : nullptr;  // (scalar lower sweeps of a small application, see there)
 		launch_sweep(a, part, post, dsrc, p->stream);
 		ph.launches++;
 		cur = out;
@@ -1653,6 +1655,20 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
 		}
+		// Small scalar applications, one launch less again: the first upper sweep of a small application reads the zeros
+		// vector, i.e. it is z1 = D^-1 y and nothing else -- the LAST lower sweep stores it beside y_i (same arithmetic:
+		// (1 / u_ii) * y_i, u_ii from the contiguous copy of the factor's diagonal), and the upper sweeps start in place
+		// from z1.  64^3, 3+3 sweeps: 5 -> 4 launches.
+		const bool fuse_z1 = small_apply && g_small_apply >= 2 && scalar && apply_init == BLASTED_HIP_INIT_A_ZERO &&
+		                     p->pat.nbrows < (1 << 20);
+		if (fuse_z1) {
+			if (!p->fdiag_valid) {
+				ensure(p->fdiag, (long)p->pat.nbrows);
+				launch_gather_diag_blocks(p->pat, p->iluvals, p->fdiag, p->stream);
+				p->fdiag_valid = true;
+			}
+			a.dvals = p->fdiag;
+		}
 		double *yother = jac ? ensure(p->tmp[0], n) : nullptr;
 		double *y;
 		if (skip_first) {
@@ -1673,9 +1689,10 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		} else if (small_apply && !p->scaled && napplysweeps >= 2)
 			// (from y0 = 0 the first lower sweep gives y1 = r exactly -- the skipped products are with zeros -- so the
 			// second one can read r as its iterate: one launch less)
-			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, dr, napplysweeps - 1, mode, 0);
+			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, dr, napplysweeps - 1, mode, 0, fuse_z1 ? dz : nullptr);
 		else
-			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, small_apply ? p->zeros : nullptr, napplysweeps, mode, 0);
+			y = run_sweeps(p, a, PART_LOWER, POST_SUB, D_NONE, p->ytemp, yother, small_apply ? p->zeros : nullptr, napplysweeps, mode, 0,
+			               fuse_z1 ? dz : nullptr);
 		double *yfree = (y == p->ytemp) ? yother : p->ytemp;  // Jacobi mode: the non-final y buffer
 
 		// z := y or z := 0, then upper sweeps, src/solverops_ilu0.cpp:110-141
@@ -1714,7 +1731,10 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 				ph.launches = 1;
 				ph.done();
 			}
-			run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, nullptr, first_in, napplysweeps, mode, 1);
+			if (fuse_z1)  // dz holds z1 already: the remaining sweeps run in place
+				run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, nullptr, nullptr, napplysweeps - 1, mode, 1);
+			else
+				run_sweeps(p, a, PART_UPPER, POST_D_SUB, dsrc, dz, nullptr, first_in, napplysweeps, mode, 1);
 		} else if (apply_init == BLASTED_HIP_INIT_A_ZERO && !scalar) {
 			// first sweep from z0 = 0: z1 = D^-1 y through the contiguous copy of the factor's diagonal blocks
 			if (!p->fdiag_valid) {
@@ -2342,6 +2362,11 @@ int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr)
 		use_device(p);
 		if (!p->iluvals || !dev_ptr)
 			BHIP_FAIL(BLASTED_HIP_ESTATE, "iluvals is not available");
+		// the caller may write through the pointer: whatever was derived from the factor is made again when next needed
+		p->fac_lvl.invalidate();
+		p->fac_nat.invalidate();
+		p->fac_applies = 0;
+		p->fdiag_valid = false;
 		*dev_ptr = p->iluvals;
 	});
 }
@@ -2458,7 +2483,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
 			g_compact_after = std::atol(spec + 13);
 		else if (spec && std::strncmp(spec, "smallapply=", 11) == 0)
-			g_small_apply = spec[11] != '0';
+			g_small_apply = spec[11] - '0';
 		else if (spec && std::strncmp(spec, "placement=", 10) == 0)
 			g_placement = spec[10] == '0' ? 0 : (spec[10] == '2' ? 2 : 1);
 		else if (spec && std::strncmp(spec, "applynone=", 10) == 0)

@@ -76,6 +76,8 @@ struct SweepArgs {
 	const double *xin;      // gathered iterate
 	double *xout;           // written iterate (== xin for in-place async sweeps)
 	double *xnat;           // level-ordered exact solves: optional second output in natural row order
+	double *z1out;          // scalar lower sweep (kernels_sweep.hip): optional second output z1_i = (1 / dvals_i) x_i, dvals =
+	                        // the factor's diagonal by row -- the first upper sweep from a zero iterate, fused (small applications)
 	double a, b;            // POST_AXPBY coefficients
 	int descending;         // row order of the sweep
 	int xcd_shift;          // log2 of the super-chunk size of the XCD-aware chunk numbering (lanes.hpp); -1 = the

@@ -37,9 +37,10 @@
 
 namespace bhip {
 
-template <int BS, bool RM, int PART, int POST, int DSRC, int UNR, bool BIG = false>
+template <int BS, bool RM, int PART, int POST, int DSRC, int UNR, bool BIG = false, bool Z1 = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
+	static_assert(!Z1 || (BS == 1 && PART == PART_LOWER && POST == POST_SUB), "fused z1: scalar lower sweep only");
 	static_assert((Geo<BS, BIG>::RCHUNK / Geo<BS, BIG>::RSTEP) % UNR == 0, "row steps per chunk must be a multiple of UNR");
 	using Ge = Geo<BS, BIG>;
 	constexpr int BSP = Ge::BSP, SUB = Ge::SUB, G = Ge::G, NB = Ge::NB, BS2 = BS * BS;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 			}
 		}
 
-		double bv[UNR][KFIX], xv[UNR][KFIX], d[UNR], rv[UNR];
+		double bv[UNR][KFIX], xv[UNR][KFIX], d[UNR], rv[UNR], dz1[UNR];
 #pragma unroll
 		for (int q = 0; q < UNR; q++) {
 #pragma unroll
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 			d[q] = 0.0;
 			if (DSRC == D_DBLOCKS && ok[q] && active && slot == 0)
 				d[q] = *reinterpret_cast<const double *>(dbase + ((unsigned)lr[q] * (unsigned)(BS2 * 8) + 8u * (unsigned)e));
+			// (Z1, scalar lower sweep: the row's u_ii from the contiguous copy of the factor's diagonal, for the fused
+			// first upper sweep)
+			double du = 1.0;
+			if (Z1 && ok[q] && slot == 0)
+				du = *reinterpret_cast<const double *>(dbase + ((unsigned)lr[q] * 8u));
+			dz1[q] = du;
 			rv[q] = 0.0;
 			if (ok[q] && r < BS && a.rhs) {
 				rv[q] = *reinterpret_cast<const double *>(rbase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
@@ -199,6 +206,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 			if (ok[q] && slot == 0 && c == 0 && r < BS) {
 				double *const dst = reinterpret_cast<double *>(obase + ((unsigned)lr[q] * (unsigned)(BS * 8) + 8u * (unsigned)r));
 				*dst = out;
+				// the arithmetic of the upper sweep with D_RECIP_DIAG whose gathered iterate is all zeros: d = 1 / u_ii,
+				// z = d * (y - 0)
+				if (Z1)
+					a.z1out[(long)r0 + lr[q]] = (1.0 / dz1[q]) * out;
 			}
 		}
 	}
@@ -274,6 +285,16 @@ void launch_sweep(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream
 {
 	if (a.pat.nbrows == 0)
 		return;  // an empty subdomain
+	if (a.z1out) {
+		// the scalar lower sweep with the first upper sweep fused into its stores (capi.hip, small applications): a.dvals
+		// is the factor's diagonal, one entry per row
+		if (a.pat.bs != 1 || part != PART_LOWER || post != POST_SUB || dsrc != D_NONE || a.pat.nbrows >= (1 << 20) || !a.dvals)
+			BHIP_FAIL(BLASTED_HIP_EINVAL, "launch_sweep: fused second output for this operator");
+		const unsigned grid = (unsigned)(((long)a.pat.nbrows + Geo<1>::RCHUNK - 1) / Geo<1>::RCHUNK);
+		hipLaunchKernelGGL((sweep_kernel<1, false, PART_LOWER, POST_SUB, D_NONE, 1, false, true>), dim3(grid), dim3(256), 0, s, a);
+		BHIP_CHECK(hipGetLastError());
+		return;
+	}
 	if (launch_sweepw(a, part, post, dsrc, s))
 		return;
 	if (launch_sweepodd(a, part, post, dsrc, s))

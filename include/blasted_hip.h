@@ -191,7 +191,9 @@ int blasted_hip_get_iluvals(blasted_hip_prec p, double *out_host);  /* nnzb*bs*b
 int blasted_hip_get_dblocks(blasted_hip_prec p, double *out_host);  /* nbrows*bs*bs */
 int blasted_hip_get_scale(blasted_hip_prec p, double *out_host);    /* nbrows*bs */
 int blasted_hip_get_ytemp(blasted_hip_prec p, double *out_host);    /* nbrows*bs */
-/* device pointer of the factor storage (benchmarks: initialise in HBM without a host copy) */
+/* device pointer of the factor storage (benchmarks, tests: initialise in HBM without a host copy).  The caller may
+ * write through it before the next call into the operator; copies the operator derived from the factor (compact
+ * triangles, its diagonal) are made again from the storage when next needed. */
 int blasted_hip_iluvals_device(blasted_hip_prec p, double **dev_ptr);
 
 /* ---- raw HBM buffers: the storage behind device_vector<T> (include/device_container.hpp:19-20,

@@ -1350,7 +1350,8 @@ def test_small_application_without_fills_converges_to_exact(golden, case, usesca
     """VERDICT r03 item 6 (the part that was kept): a cache-resident problem's asynchronous ILU(0) application runs as
     2 s launches instead of 2 s + 2 -- the first sweep of each triangle reads an operator-owned vector of zeros instead of
     a freshly zeroed iterate -- and reaches the oracle's exact solves like the form with the fills (`smallapply=0`), from
-    both initial guesses, with and without scaling, for device and host vectors."""
+    both initial guesses, with and without scaling, for device and host vectors.  Scalar matrices (`smallapply=2`, the
+    default) save one more launch: the last lower sweep stores z1 = D^-1 y beside y, the upper sweeps start from it."""
     import torch
     m = matrices(golden)[case]()
     n = m["nbrows"] * m["bs"]
@@ -1364,7 +1365,7 @@ def test_small_application_without_fills_converges_to_exact(golden, case, usesca
     s = nlev + 2
     rd = torch.from_numpy(r).cuda()
     try:
-        for small in ("1", "0"):
+        for small in ("2", "1", "0"):
             capi.set_tuning("smallapply=" + small)
             for init in (capi.INIT_A_ZERO, capi.INIT_A_JACOBI):
                 z = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")   # whatever the caller's z held
@@ -1376,11 +1377,50 @@ def test_small_application_without_fills_converges_to_exact(golden, case, usesca
                 assert rel(z.cpu().numpy(), exact) < TOL_EXACT, (small, init)
                 assert rel(p.get_ytemp(), ey) < TOL_EXACT
                 launches = t["lower_launches"] + t["upper_launches"] + t["other_launches"]
-                fills = (0 if small == "1" else 1 + (init == capi.INIT_A_ZERO)) + (1 if usescale else 0)  # (+ z := S z)
-                # (unscaled: the first lower sweep from zero is y1 = r, so the second one reads r -- one launch less)
-                assert launches == 2 * s + fills - (1 if small == "1" and not usescale else 0)
+                fills = (0 if small != "0" else 1 + (init == capi.INIT_A_ZERO)) + (1 if usescale else 0)  # (+ z := S z)
+                # (unscaled: the first lower sweep from zero is y1 = r, so the second one reads r -- one launch less;
+                #  scalar, from zero: the first upper sweep rides on the last lower one -- one less again)
+                fused = small == "2" and m["bs"] == 1 and init == capi.INIT_A_ZERO
+                assert launches == 2 * s + fills - (1 if small != "0" and not usescale else 0) - (1 if fused else 0)
             zh = p.ilu0_apply(r, s, mode=capi.ASYNC)            # host vectors
             assert rel(zh, exact) < TOL_EXACT
     finally:
-        capi.set_tuning("smallapply=1")
+        capi.set_tuning("smallapply=2")
         p.close()
+
+
+@pytest.mark.parametrize("case", ["poisson16_csr", "2dcyl1_csr", "random_csr"])
+@pytest.mark.parametrize("usescale", [False, True])
+def test_small_scalar_application_with_the_fused_first_upper_sweep(golden, case, usescale):
+    """The fused form against the unfused one where both are deterministic: ONE sweep per triangle of a small
+    application reads the zeros vector, i.e. y = S r, z = S D^-1 y whatever the order of the rows (every product of the
+    sweeps is with a zero) -- bit for bit the same with `smallapply=2` (one launch) and `=1` (two), and equal to the
+    oracle's synchronous sweep.  (`=0`, in place on freshly zeroed iterates, sees rows the sweep has already written.)"""
+    import torch
+    m = matrices(golden)[case]()
+    n = m["nbrows"]
+    r = W.rhs_vector(n)
+    p = make_prec(m)
+    p.ilu0_factorize(-1, usescale=usescale)
+    f = p.get_iluvals()
+    scale = p.get_scale() if usescale else None
+    want = O.ilu0_apply(m, f, r, 1, mode=O.JACOBI_SYNC, scale=scale)
+    rd = torch.from_numpy(r).cuda()
+    got = {}
+    try:
+        for small in ("2", "1"):
+            capi.set_tuning("smallapply=" + small)
+            z = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+            p.set_timing(True)
+            p.get_timing()
+            p.ilu0_apply(rd, 1, init=capi.INIT_A_ZERO, mode=capi.ASYNC, out=z)
+            t = p.get_timing()
+            p.set_timing(False)
+            got[small] = (z.cpu().numpy(), p.get_ytemp(), t["lower_launches"] + t["upper_launches"])
+    finally:
+        capi.set_tuning("smallapply=2")
+        p.close()
+    assert got["2"][2] == 1 and got["1"][2] == 2
+    assert np.array_equal(got["2"][1], got["1"][1])      # y
+    assert np.array_equal(got["2"][0], got["1"][0])      # z
+    assert rel(got["2"][0], want) < 1e-14
