@@ -2522,7 +2522,7 @@ int blasted_hip_set_tuning(const char *spec)
 		else if (spec && std::strncmp(spec, "sweepwr=", 8) == 0)
 			set_sweepwr_enabled(spec[8] != '0');
 		else if (spec && std::strncmp(spec, "sweepodd=", 9) == 0)
-			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : (std::strncmp(spec + 9, "kf", 2) == 0 ? 10 + std::atoi(spec + 11) : spec[9] != '0')))));
+			set_sweepodd_enabled(std::strcmp(spec + 9, "nt1") == 0 ? 2 : (std::strcmp(spec + 9, "nt0") == 0 ? 3 : (std::strcmp(spec + 9, "occ1") == 0 ? 4 : (std::strcmp(spec + 9, "occ0") == 0 ? 5 : spec[9] != '0'))));
 		else if (spec && std::strncmp(spec, "factorfuse=", 11) == 0)
 			g_factor_fuse_init = spec[11] - '0';
 		else if (spec && std::strncmp(spec, "factor1plan=", 12) == 0)

@@ -79,6 +79,14 @@ __device__ __forceinline__ double inverse_b_layout(const double v, const int k, 
 // Round 4, after request-ahead had paid in kernels_factorodd.hip (12-25 %): here, at the same eight waves and 62
 // registers, the operand blocks of pair k + 1 requested before the product of pair k cost 1.5 %, and the position of a
 // lower block's u_jj requested one block ahead 10 % (profiles/r04_factor4_pipe_ab.txt).  Not kept.
+//
+// RM (round 4): ROW-major blocks (the reference instantiates bs = 4 RowMajor for its own drivers,
+// src/solverops_ilu0.cpp:390).  A row-major block is the column-major image of its transpose, so the kernel works on
+// X' = X^T throughout: U'_ij = A'_ij - sum U'_kj L'_ik (the two operand loads swap their element offsets, the product
+// its operands) and L'_ij = inverse(U'_jj) S' -- a product from the LEFT: S' comes out in D layout, which is also the
+// B-operand layout, and inverse(U'_jj) = inverse(U_jj)^T in A-operand layout is inverse(U_jj) in B-operand layout,
+// i.e. what inverse_b_layout returns when u_jj is loaded with the transposed offsets.  No role swap for lower blocks.
+template <bool RM>
 __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 {
 	__shared__ int s_rp[F4_RCHUNK + 1];
@@ -129,15 +137,15 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 			// (sweeps after the first, in place: an upper block without pairs already holds its value, a_ij)
 			const bool valid = inrow && !(a.skip_fixed && col > irow && ke == kb);
 			const bool lower = valid && irow > col;
-			// lower blocks work on S^T (A-operand layout), the others on S (D layout)
-			const int offS = lower ? offA : offD;
+			// lower blocks work on S^T (A-operand layout), the others on S (D layout); row-major: everything on S' (D layout)
+			const int offS = (lower && !RM) ? offA : offD;
 			double sval = valid ? a.avals[(long)jpos * 16 + offS] : 0.0;
 			double dval = 0.0;  // U_jj in B-operand layout, lower blocks only
 			if (lower)
-				dval = a.in[(long)a.pat.diagind[col] * 16 + offD];
+				dval = a.in[(long)a.pat.diagind[col] * 16 + (RM ? offA : offD)];
 			if (a.scale && valid) {
-				// (r,c) of this lane's entry: D layout (k, m); transposed layout (m, k)
-				const int r = lower ? m : k, c = lower ? k : m;
+				// (r,c) of this lane's entry: D layout (k, m); transposed layout (m, k); row-major D layout holds X'(k, m) = X(m, k)
+				const int r = (lower || RM) ? m : k, c = (lower || RM) ? k : m;
 				sval *= a.scale[(long)irow * 4 + r] * a.scale[(long)col * 4 + c];
 			}
 
@@ -163,19 +171,23 @@ __global__ __launch_bounds__(256) void factor4_kernel(const FactorArgs a)
 					// reorder them: `out` is not restrict-qualified and the accesses may alias).  No other wave writes
 					// this row.  tests/test_gpu_parity.py::test_fused_initialisation_builds_the_same_factor runs the
 					// fused build on factor storage POISONED with another matrix's factor: a stale read would surface.)
-					lval = (a.lrow_fresh ? a.out : a.in)[(long)lp * 16 + offA];
-					uval = a.in[(long)up * 16 + offD];
+					lval = (a.lrow_fresh ? a.out : a.in)[(long)lp * 16 + (RM ? offD : offA)];
+					uval = a.in[(long)up * 16 + (RM ? offA : offD)];
 				}
-				// upper/diag: sum += L U ; lower: sum^T += U^T L^T (same loads, roles swapped)
-				acc = mfma444(lower ? uval : lval, lower ? lval : uval, acc);
+				// upper/diag: sum += L U ; lower: sum^T += U^T L^T (same loads, roles swapped); row-major: sum' += U' L'
+				if (RM)
+					acc = mfma444(uval, lval, acc);
+				else
+					acc = mfma444(lower ? uval : lval, lower ? lval : uval, acc);
 			}
 			double res = sval - acc;
 
 			if (__any(lower)) {
 				const double inv = inverse_b_layout(lower ? dval : ((k == m) ? 1.0 : 0.0), k, b4, m);
-				const double prod = mfma444(lower ? res : 0.0, lower ? inv : 0.0, 0.0);
+				const double prod = RM ? mfma444(lower ? inv : 0.0, lower ? res : 0.0, 0.0)
+				                       : mfma444(lower ? res : 0.0, lower ? inv : 0.0, 0.0);
 				if (lower)
-					res = prod;  // S * inverse(U_jj), D layout
+					res = prod;  // S * inverse(U_jj), D layout (row-major: inverse(U'_jj) * S')
 			}
 
 			if (valid) {
@@ -647,10 +659,13 @@ bool launch_factor4(const FactorArgs &a, hipStream_t s)
 		const char *e = std::getenv("BLASTED_HIP_FACTOR4");
 		g_factor4_enabled = (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 	}
-	if (!g_factor4_enabled || a.pat.bs != 4 || a.pat.rowmajor || a.pat.nbrows == 0)
+	if (!g_factor4_enabled || a.pat.bs != 4 || a.pat.nbrows == 0)
 		return false;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F4_RCHUNK - 1) / F4_RCHUNK);
-	hipLaunchKernelGGL(factor4_kernel, dim3(grid), dim3(256), 0, s, a);
+	if (a.pat.rowmajor)
+		hipLaunchKernelGGL(factor4_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+	else
+		hipLaunchKernelGGL(factor4_kernel<false>, dim3(grid), dim3(256), 0, s, a);
 	BHIP_CHECK(hipGetLastError());
 	return true;
 }

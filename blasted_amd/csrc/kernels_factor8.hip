@@ -44,7 +44,11 @@ __device__ __forceinline__ double mfma444(const double a, const double b, const 
 
 constexpr int F8_MW = 4, F8_ML = 3, F8_MP = 4;  // the fast path's window: blocks with work, lower ones, pairs
 
-template <bool INPLACE_FAST>
+// RM (round 4): ROW-major blocks = the column-major image of the transposed blocks; the kernel then works on X' = X^T:
+// S' = A' - sum U'_kj L'_ik (the two blocks of a pair swap their operand roles) and L'_ij = inverse(U'_jj) S' (a product
+// from the left: the inverse is read in A-operand layout from the side array -- the pre-pass inverts in the blocks' own
+// layout -- and S' is re-read in B-operand layout with two shuffles).
+template <bool INPLACE_FAST, bool RM>
 __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const double *dinv)
 {
 	__shared__ int s_rp[F8_RCHUNK + 1];
@@ -65,6 +69,14 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 	const int offB1 = (4 * tj + m) * 8 + 4 + k;        // (r = 4+k,   c = 4tj+m)  tk = 1
 	const int srcA0 = 16 * m + 4 * (2 * ti + 0) + k;   // lane holding S(4ti+m, k)   in D layout
 	const int srcA1 = 16 * m + 4 * (2 * ti + 1) + k;   // lane holding S(4ti+m, 4+k)
+	const int srcB0 = 16 * k + 4 * (0 + tj) + m;       // lane holding S(k,   4tj+m) in D layout (row-major form)
+	const int srcB1 = 16 * k + 4 * (2 + tj) + m;       // lane holding S(4+k, 4tj+m)
+	// what the second factor of a product S x (or x S') is read with, and the shuffles that re-read a result as the
+	// first (column-major) or the second (row-major) factor
+	const int offX0 = RM ? offA0 : offB0, offX1 = RM ? offA1 : offB1;
+	const int srcS0 = RM ? srcB0 : srcA0, srcS1 = RM ? srcB1 : srcA1;
+	// the scaling factors of this lane's entry: D layout holds X(4ti+k, 4tj+m), row-major X'(4ti+k, 4tj+m) = X(4tj+m, 4ti+k)
+	const int scr = RM ? 4 * tj + m : 4 * ti + k, scc = RM ? 4 * ti + k : 4 * tj + m;
 
 	const int nb = a.pat.nbrows;
 	const unsigned chunk = xcd_chunk(blockIdx.x, gridDim.x);
@@ -127,8 +139,8 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 					av[e] = work[e] ? a.avals[(long)(jbeg + e) * 64 + offD] : 0.0;
 #pragma unroll
 				for (int e = 0; e < F8_ML; e++) {
-					dv[e][0] = low[e] ? dinv[(long)col[e] * 64 + offB0] : 0.0;
-					dv[e][1] = low[e] ? dinv[(long)col[e] * 64 + offB1] : 0.0;
+					dv[e][0] = low[e] ? dinv[(long)col[e] * 64 + offX0] : 0.0;
+					dv[e][1] = low[e] ? dinv[(long)col[e] * 64 + offX1] : 0.0;
 					lres[e][0] = lres[e][1] = 0.0;
 				}
 #pragma unroll
@@ -136,14 +148,14 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 					const int pidx = q < np ? pb - plo + q : 0;
 					const int up = __builtin_amdgcn_readfirstlane(s_up[pidx]);
 					slot[q] = __builtin_amdgcn_readfirstlane(s_lp[pidx]) - jbeg;
-					uo[q][0] = q < np ? a.in[(long)up * 64 + offB0] : 0.0;
-					uo[q][1] = q < np ? a.in[(long)up * 64 + offB1] : 0.0;
+					uo[q][0] = q < np ? a.in[(long)up * 64 + offX0] : 0.0;
+					uo[q][1] = q < np ? a.in[(long)up * 64 + offX1] : 0.0;
 				}
 				if (a.scale) {
 #pragma unroll
 					for (int e = 0; e < F8_MW; e++)
 						if (work[e])
-							av[e] *= a.scale[(long)irow * 8 + 4 * ti + k] * a.scale[(long)col[e] * 8 + 4 * tj + m];
+							av[e] *= a.scale[(long)irow * 8 + scr] * a.scale[(long)col[e] * 8 + scc];
 				}
 #pragma unroll
 				for (int e = 0; e < F8_MW; e++) {
@@ -159,18 +171,18 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 								l0 = slot[q] == t ? lres[t][0] : l0;
 								l1 = slot[q] == t ? lres[t][1] : l1;
 							}
-							acc = mfma444(l0, uo[q][0], acc);
-							acc = mfma444(l1, uo[q][1], acc);
+							acc = RM ? mfma444(uo[q][0], l0, acc) : mfma444(l0, uo[q][0], acc);
+							acc = RM ? mfma444(uo[q][1], l1, acc) : mfma444(l1, uo[q][1], acc);
 						}
 					}
 					double res = av[e] - acc;
 					if (e < F8_ML && low[e]) {
-						const double sa0 = __shfl(res, srcA0, 64), sa1 = __shfl(res, srcA1, 64);
-						double prod = mfma444(sa0, dv[e][0], 0.0);
-						prod = mfma444(sa1, dv[e][1], prod);
+						const double sa0 = __shfl(res, srcS0, 64), sa1 = __shfl(res, srcS1, 64);
+						double prod = RM ? mfma444(dv[e][0], sa0, 0.0) : mfma444(sa0, dv[e][0], 0.0);
+						prod = RM ? mfma444(dv[e][1], sa1, prod) : mfma444(sa1, dv[e][1], prod);
 						res = prod;
-						lres[e][0] = __shfl(res, srcA0, 64);
-						lres[e][1] = __shfl(res, srcA1, 64);
+						lres[e][0] = __shfl(res, srcS0, 64);
+						lres[e][1] = __shfl(res, srcS1, 64);
 					}
 					a.out[(long)(jbeg + e) * 64 + offD] = res;
 				}
@@ -200,11 +212,11 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 			double sval = a.avals[(long)jpos * 64 + offD];
 			double d0 = 0.0, d1 = 0.0;
 			if (lower) {
-				d0 = dinv[(long)col * 64 + offB0];
-				d1 = dinv[(long)col * 64 + offB1];
+				d0 = dinv[(long)col * 64 + offX0];
+				d1 = dinv[(long)col * 64 + offX1];
 			}
 			if (a.scale)
-				sval *= a.scale[(long)irow * 8 + 4 * ti + k] * a.scale[(long)col * 8 + 4 * tj + m];
+				sval *= a.scale[(long)irow * 8 + scr] * a.scale[(long)col * 8 + scc];
 
 			double acc = 0.0;
 			for (int kk = kb; kk < ke; kk++) {
@@ -218,17 +230,18 @@ __global__ __launch_bounds__(256) void factor8_kernel(const FactorArgs a, const 
 					up = a.upperp[kk];
 				}
 				const double *const lblk = (a.lrow_fresh ? a.out : a.in) + (long)lp * 64, *const ublk = a.in + (long)up * 64;
-				const double l0 = lblk[offA0], l1 = lblk[offA1];
-				const double u0 = ublk[offB0], u1 = ublk[offB1];
+				const double *const first = RM ? ublk : lblk, *const second = RM ? lblk : ublk;
+				const double l0 = first[offA0], l1 = first[offA1];
+				const double u0 = second[offB0], u1 = second[offB1];
 				acc = mfma444(l0, u0, acc);
 				acc = mfma444(l1, u1, acc);
 			}
 			double res = sval - acc;
 
 			if (lower) {
-				const double sa0 = __shfl(res, srcA0, 64), sa1 = __shfl(res, srcA1, 64);
-				double prod = mfma444(sa0, d0, 0.0);
-				prod = mfma444(sa1, d1, prod);
+				const double sa0 = __shfl(res, srcS0, 64), sa1 = __shfl(res, srcS1, 64);
+				double prod = RM ? mfma444(d0, sa0, 0.0) : mfma444(sa0, d0, 0.0);
+				prod = RM ? mfma444(d1, sa1, prod) : mfma444(sa1, d1, prod);
 				res = prod;
 			}
 
@@ -255,15 +268,21 @@ bool launch_factor8(const FactorArgs &a, double *dinv_scratch, hipStream_t s)
 		const char *e = std::getenv("BLASTED_HIP_FACTOR8");
 		g_factor8_enabled = (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 	}
-	if (!g_factor8_enabled || !dinv_scratch || a.pat.bs != 8 || a.pat.rowmajor || a.pat.nbrows == 0)
+	if (!g_factor8_enabled || !dinv_scratch || a.pat.bs != 8 || a.pat.nbrows == 0)
 		return false;
 	launch_invert_diag_blocks(a.pat, a.in, 1, dinv_scratch, 0, s);
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + F8_RCHUNK - 1) / F8_RCHUNK);
 	// (tuning "factor8=2": in-place sweeps with the block-by-block loop only, the round-2 kernel)
-	if (a.in == a.out && g_factor8_enabled != 2)
-		hipLaunchKernelGGL(factor8_kernel<true>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+	const bool fast = a.in == a.out && g_factor8_enabled != 2;
+	if (a.pat.rowmajor) {
+		if (fast)
+			hipLaunchKernelGGL((factor8_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+		else
+			hipLaunchKernelGGL((factor8_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+	} else if (fast)
+		hipLaunchKernelGGL((factor8_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
 	else
-		hipLaunchKernelGGL(factor8_kernel<false>, dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
+		hipLaunchKernelGGL((factor8_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, (const double *)dinv_scratch);
 	BHIP_CHECK(hipGetLastError());
 	return true;
 }

@@ -36,7 +36,10 @@ typedef fd2_t fd2u_t __attribute__((aligned(8)));
 // PROBE (measurements only, tuning "factorprobe=1..5", WRONG results): 1 = the block products skip the LDS tiles (each
 // lane multiplies its own entries), 2 = the operand blocks of the pairs are not loaded (the matrix block stands in),
 // 3 = no pairs at all and no store, 4 = no pairs, no matrix block, no inverse (indices + store), 5 = indices only
-template <int BS, int PROBE = 0>
+// RM: ROW-major blocks -- the column-major image of the transposed blocks, so every product is taken the other way
+// round (U'_kj L'_ik, inverse(U'_jj) S'; the inverse of the transposed block is the transposed inverse, which is what the
+// pre-pass leaves in row-major storage) and the scaling factors swap their roles.
+template <int BS, int PROBE = 0, bool RM = false>
 __global__ __launch_bounds__(256, 7) void factorodd_kernel(const FactorArgs a, const double *__restrict__ dinv)
 {
 	static_assert(BS == 5 || BS == 7, "odd block sizes 5, 7");
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(256, 7) void factorodd_kernel(const FactorArgs a, c
 		if (PROBE >= 4)
 			s.x = s.y = (double)(col + kend);
 		if (a.scale && actB) {
-			s.x *= a.scale[(long)irow * BS + rA] * a.scale[(long)col * BS + cA];
-			s.y *= a.scale[(long)irow * BS + rB] * a.scale[(long)col * BS + cB];
+			// (row-major: this lane's entry (rA, cA) of the column-major image is entry (cA, rA) of the block)
+			s.x *= a.scale[(long)irow * BS + (RM ? cA : rA)] * a.scale[(long)col * BS + (RM ? rA : cA)];
+			s.y *= a.scale[(long)irow * BS + (RM ? cB : rB)] * a.scale[(long)col * BS + (RM ? rB : cB)];
 		}
 		fd2_t dv;
 		dv.x = dv.y = 0.0;
@@ -143,13 +147,19 @@ __global__ __launch_bounds__(256, 7) void factorodd_kernel(const FactorArgs a, c
 				uv = *reinterpret_cast<const fd2u_t *>(a.in + (long)upos * BS2 + boff);
 			}
 			double pA, pB;
-			gemm(lv, uv, pA, pB);
+			if (RM)
+				gemm(uv, lv, pA, pB);
+			else
+				gemm(lv, uv, pA, pB);
 			s.x -= pA;
 			s.y -= pB;
 		}
 		if (irow > col && PROBE < 4) {
 			double pA, pB;
-			gemm(s, dv, pA, pB);
+			if (RM)
+				gemm(dv, s, pA, pB);
+			else
+				gemm(s, dv, pA, pB);
 			s.x = pA;
 			s.y = pB;
 		}
@@ -190,8 +200,7 @@ bool launch_factorodd(const FactorArgs &a, double *dinv_scratch, hipStream_t s)
 		g_factorodd_enabled = (e && std::strcmp(e, "0") == 0) ? 0 : 1;
 	}
 	const int bs = a.pat.bs;
-	if (!g_factorodd_enabled || !dinv_scratch || (bs != 5 && bs != 7) || a.pat.rowmajor || a.pat.nbrows == 0 ||
-	    a.rows)
+	if (!g_factorodd_enabled || !dinv_scratch || (bs != 5 && bs != 7) || a.pat.nbrows == 0 || a.rows)
 		return false;
 	launch_invert_diag_blocks(a.pat, a.in, 1, dinv_scratch, 0, s);
 	launch_factorodd_rows(a, dinv_scratch, s);
@@ -220,10 +229,16 @@ static void launch_factorodd_rows(const FactorArgs &a, const double *dinv, hipSt
 			hipLaunchKernelGGL((factorodd_kernel<5, 5>), dim3(grid), dim3(256), 0, s, a, dinv);
 		else
 #endif
+		if (a.pat.rowmajor)
+			hipLaunchKernelGGL((factorodd_kernel<5, 0, true>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else
 			hipLaunchKernelGGL(factorodd_kernel<5>, dim3(grid), dim3(256), 0, s, a, dinv);
 	} else {
 		const unsigned grid = (unsigned)((n + 7) / 8);
-		hipLaunchKernelGGL(factorodd_kernel<7>, dim3(grid), dim3(256), 0, s, a, dinv);
+		if (a.pat.rowmajor)
+			hipLaunchKernelGGL((factorodd_kernel<7, 0, true>), dim3(grid), dim3(256), 0, s, a, dinv);
+		else
+			hipLaunchKernelGGL(factorodd_kernel<7>, dim3(grid), dim3(256), 0, s, a, dinv);
 	}
 }
 

