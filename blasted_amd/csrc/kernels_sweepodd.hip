@@ -54,7 +54,12 @@ __device__ __forceinline__ d2_t load16u_nt(const char *p)
 // need the same number of load rounds (config 4: a wave's four rows average 7 blocks where its longest has 11-12) --
 // 3-4 % slower, profiles/r04_sweepodd_balanced_ab.txt; six or eight straight-line block passes instead of four for the
 // triangular sweeps (70-79 / 86-95 registers): +0.6 % / -7 % on config 4, same file.)
-template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1>
+// RM (round 4): ROW-major blocks.  The lanes hold the same 16-byte pieces of a block; entry e of the stored image is
+// then A(e / bs, e % bs): it multiplies x_{e % bs} and belongs to component e / bs, i.e. the roles of the two indices
+// swap -- the partial products of a component are CONTIGUOUS in the tile, and the x pair a lane gathers is
+// (x_{e % bs}, x_{e % bs + 1}) except where its second entry wraps into the next row of the block and wants x_0, which
+// the group's first lane holds (one lane permute per pass).
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool NT = true, int OCC = 1, bool RM = false>
 __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 {
 	static_assert(BS == 3 || BS == 5 || BS == 7, "odd block sizes 3, 5, 7");
@@ -79,9 +84,13 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 	const bool actA = t < L - 1, actB = t < L;
 	const int eA = actA ? 2 * t : BS2 - 2, eB = actA ? 2 * t + 1 : BS2 - 1;
 	const unsigned boff = actA ? 16u * (unsigned)t : 8u * (unsigned)(BS2 - 2);  // last lane: the last two entries
-	const int cA = (eA / BS) < BS ? eA / BS : BS - 1, cB = (eB / BS) < BS ? eB / BS : BS - 1;
+	// the index of x (and of the vector D multiplies) that this lane's two entries go with: their column, row-major their
+	// position inside the row of the block
+	const int cA = RM ? eA % BS : ((eA / BS) < BS ? eA / BS : BS - 1), cB = RM ? eB % BS : ((eB / BS) < BS ? eB / BS : BS - 1);
 	const int cx = cA < BS - 2 ? cA : BS - 2;  // gathered pair (x_cx, x_cx+1)
 	const bool hiA = cA != cx, hiB = cB != cx;
+	const bool wrapB = RM && cB == 0 && cA == BS - 1;  // second entry = first of the block's next row: x_0
+	const int lane0 = (threadIdx.x & 63) & ~(G - 1);   // the group's first lane (entries 0, 1: its pair starts at x_0)
 
 	const int nb = a.pat.nbrows;
 	// (default here: the XCDs take turns on 64 chunks = 8192 rows, not 16 -- on the unstructured configuration an XCD
@@ -180,8 +189,9 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 				if (DIAG_RIDES && k == 0) {
 					dv = q.bv[0];  // item 0 of the row is its diagonal block: xv[0] was not loaded (zero)
 				} else {
+					const double x0 = RM ? __shfl(q.xv[k].x, lane0, 64) : 0.0;
 					accA += q.bv[k].x * (hiA ? q.xv[k].y : q.xv[k].x);
-					accB += q.bv[k].y * (hiB ? q.xv[k].y : q.xv[k].x);
+					accB += q.bv[k].y * (wrapB ? x0 : (hiB ? q.xv[k].y : q.xv[k].x));
 				}
 			}
 			// rows longer than KFIX blocks (unstructured meshes: ~7 lower and ~8 diagonal+upper blocks at 14
@@ -207,8 +217,9 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 				}
 #pragma unroll
 				for (int k = 0; k < KGRP; k++) {
+					const double x0 = RM ? __shfl(x4[k].x, lane0, 64) : 0.0;
 					accA += v4[k].x * (hiA ? x4[k].y : x4[k].x);
-					accB += v4[k].y * (hiB ? x4[k].y : x4[k].x);
+					accB += v4[k].y * (wrapB ? x0 : (hiB ? x4[k].y : x4[k].x));
 				}
 			}
 		}
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 			if (t < BS) {
 #pragma unroll
 				for (int cc = 0; cc < BS; cc++)
-					sum += tile[cc * BS + t];
+					sum += RM ? tile[t * BS + cc] : tile[cc * BS + t];
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256, OCC) void sweepodd_kernel(const SweepArgs a)
 			if (t < BS) {
 #pragma unroll
 				for (int cc = 0; cc < BS; cc++)
-					pr += tile[cc * BS + t];
+					pr += RM ? tile[t * BS + cc] : tile[cc * BS + t];
 			}
 			__builtin_amdgcn_wave_barrier();
 			out = (POST == POST_D_SUB) ? pr : rv - pr;
@@ -286,7 +297,9 @@ void launch5(const SweepArgs &a, hipStream_t s)
 	// passes cost them 21 registers -- SpMV at bs=5 0.69 -> 0.78 ms without the bound)
 	constexpr int OCCT = (PART == PART_LOWER || PART == PART_UPPER) ? 6 : ((PART == PART_ALL || PART == PART_OFFDIAG) ? 5 : 1);
 #define BHIP_ODD(B)                                                                                                    \
-	if (g_sweepodd_nt)                                                                                                 \
+	if (a.pat.rowmajor)                                                                                                \
+		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, OCCT, true>), dim3(grid), dim3(256), 0, s, a); \
+	else if (g_sweepodd_nt)                                                                                            \
 		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, true, 1>), dim3(grid), dim3(256), 0, s, a);    \
 	else if (g_sweepodd_occ)                                                                                           \
 		hipLaunchKernelGGL((sweepodd_kernel<B, PART, POST, DSRC, RCHUNK, false, OCCT>), dim3(grid), dim3(256), 0, s, a); \
@@ -316,7 +329,7 @@ void set_sweepodd_enabled(int on)
 bool launch_sweepodd(const SweepArgs &a, Part part, Post post, DSrc dsrc, hipStream_t s)
 {
 	const int bs = a.pat.bs;
-	if (!g_sweepodd_enabled || (bs != 3 && bs != 5 && bs != 7) || a.pat.rowmajor || a.pat.nbrows == 0)
+	if (!g_sweepodd_enabled || (bs != 3 && bs != 5 && bs != 7) || a.pat.nbrows == 0)
 		return false;
 	// 8-byte aligned arrays are all this kernel needs
 	bool ok = true;

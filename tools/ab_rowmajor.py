@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """A/B of the tuned row-major bs=4/8 sweep kernel (tuning "sweepwr=0/1") beside the column-major one on the
-same matrix with transposed blocks."""
+same matrix with transposed blocks; `ab_rowmajor.py odd`: bs = 5 / 7 / 3 (kernels_sweepodd.hip: "sweepodd=0" is the
+general kernel the row-major blocks of these sizes went through before round 4)."""
 import sys, time, torch
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from blasted_amd import capi, workloads as W
 dev = torch.device("cuda", 0)
-for bs in (4, 8):
-    n = 160 if bs == 4 else 100
+ODD = len(sys.argv) > 1 and sys.argv[1] == "odd"
+for bs in ((5, 7, 3) if ODD else (4, 8)):
+    n = {4: 160, 8: 100, 5: 110, 7: 90, 3: 140}[bs]
     m = W.poisson3d_device(n, bs, dev, grid="uniform")
     # row-major copy: transpose every block
     v = m["vals"].view(-1, bs, bs).transpose(1, 2).contiguous().view(-1)
@@ -14,7 +16,7 @@ for bs in (4, 8):
     r = W.rhs_vector_device(m["nbrows"] * bs, dev); z = torch.zeros_like(r)
     for name, mm in (("colmajor", m), ("rowmajor", mr)):
         p = capi.Prec(0, torch.cuda.current_stream().cuda_stream); p.set_matrix(mm); p.ilu0_factorize(2); p.jacobi_compute()
-        for spec in ("sweepwr=0", "sweepwr=1"):
+        for spec in (("sweepodd=0", "sweepodd=1") if ODD else ("sweepwr=0", "sweepwr=1")):
             capi.set_tuning(spec)
             def t(fn, reps=10):
                 fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
