@@ -339,7 +339,21 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	std::vector<std::pair<size_t, size_t>> mapped;
 	std::vector<hipMemGenericAllocationHandle_t> held;  // turned-down pieces and spacers: allocated until the search is over
 	size_t held_bytes = 0;
-	const size_t budget = place_budget(total);
+	size_t budget = place_budget(total);
+	// What an earlier search of this entry point still holds back (its release is deferred to the end of the call) counts
+	// as used: a search for `ytemp` that had to step over most of a class (up to 96 GiB of consecutive allocations come
+	// from one class) once left the searches for the two copies behind it no room at all -- every piece of theirs was
+	// kept unchecked, and all of them happened to lie in the wrong class (profiles/r04_bench_starved_search.txt:
+	// 299 sweeps/s instead of 326-334).  A search that finds itself short therefore hands that memory back FIRST
+	// (and waits for the driver's wipe, once) instead of going without.
+	{
+		const size_t enough = total + (g_placement >= 2 ? (size_t)64 << 30 : (size_t)8 << 30);
+		if (budget < enough && release_deferred()) {
+			if (trace)
+				std::fprintf(stderr, "[blasted_hip] placed_alloc: %zu MiB of room for the search; released what earlier searches held back\n", budget >> 20);
+			budget = place_budget(total);
+		}
+	}
 	const double budget_ms = place_budget_ms(bytes);
 	// Every candidate piece is looked at in an address range of its own (never used again) and only a piece that is kept is
 	// mapped into the buffer: no address is ever mapped twice (see tracked_free for what that is about).
