@@ -165,18 +165,22 @@ static int g_placement = [] {
 // not between one buffer's search and the next: the driver wipes released memory and makes the next allocation wait for
 // it, and inside one application three buffers are placed one after the other (6 s of waiting seen, for searches that
 // take 0.1 s when nothing is being wiped).
-static std::vector<hipMemGenericAllocationHandle_t> g_deferred_release;
+struct HeldPiece {
+	hipMemGenericAllocationHandle_t h;
+	size_t bytes;
+};
+static std::vector<HeldPiece> g_deferred_release;
 static std::mutex g_deferred_mu;  // (operators of different threads share the list)
 
 static bool release_deferred()  // true: there was something to release
 {
-	std::vector<hipMemGenericAllocationHandle_t> mine;
+	std::vector<HeldPiece> mine;
 	{
 		std::lock_guard<std::mutex> lk(g_deferred_mu);
 		mine.swap(g_deferred_release);
 	}
-	for (auto hd : mine)
-		(void)hipMemRelease(hd);
+	for (const auto &hp : mine)
+		(void)hipMemRelease(hp.h);
 	return !mine.empty();
 }
 
@@ -337,7 +341,19 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	acc.location = prop.location;
 	acc.flags = hipMemAccessFlagsProtReadWrite;
 	std::vector<std::pair<size_t, size_t>> mapped;
-	std::vector<hipMemGenericAllocationHandle_t> held;  // turned-down pieces and spacers: allocated until the search is over
+	std::vector<HeldPiece> held;  // turned-down pieces and spacers: allocated until the search is over
+	// The pieces earlier searches of this call looked at and turned down are looked at FIRST (they are allocated anyway, and
+	// what one buffer must not share is often what the next one should: the pieces the lower copy turned down for lying in
+	// ytemp's class are the ones the upper copy prefers): a search then begins with what the others have learnt about the
+	// driver's free memory instead of stepping over the same stretch again.
+	std::vector<HeldPiece> pool;
+	if (bytes > piece) {
+		std::lock_guard<std::mutex> lk(g_deferred_mu);
+		std::vector<HeldPiece> rest;
+		for (const auto &hp : g_deferred_release)
+			(hp.bytes == piece ? pool : rest).push_back(hp);
+		g_deferred_release.swap(rest);
+	}
 	size_t held_bytes = 0;
 	size_t budget = place_budget(total);
 	// What an earlier search of this entry point still holds back (its release is deferred to the end of the call) counts
@@ -355,12 +371,15 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 		}
 	}
 	const double budget_ms = place_budget_ms(bytes);
+	long from_pool = 0;
 	// Every candidate piece is looked at in an address range of its own (never used again) and only a piece that is kept is
 	// mapped into the buffer: no address is ever mapped twice (see tracked_free for what that is about).
-	const size_t max_tries = total / piece + 2 + budget / piece;
+	const size_t max_tries = total / piece + 2 + budget / piece + pool.size();
 	char *scratch = nullptr;
 	if (hipMemAddressReserve(reinterpret_cast<void **>(&scratch), max_tries * piece, 0, nullptr, 0) != hipSuccess) {
 		(void)hipGetLastError();
+		std::lock_guard<std::mutex> lk(g_deferred_mu);
+		g_deferred_release.insert(g_deferred_release.end(), pool.begin(), pool.end());
 		return nullptr;  // (the buffer's own range is kept reserved: address space is not scarce)
 	}
 	size_t tries = 0;
@@ -400,14 +419,15 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 				continue;
 			}
 		}
+		const bool pooled = sz == piece && !pool.empty() && now_ms() - t_start < budget_ms;
 		// after two misses in a row: step over a larger stretch of the driver's free memory without looking at it
-		if (misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget && now_ms() - t_start < budget_ms) {
+		if (!pooled && misses >= 2 && held_bytes + ((size_t)2 << 30) <= budget && now_ms() - t_start < budget_ms) {
 			size_t sp = (size_t)1 << (30 + (misses < 6 ? misses - 1 : 5));  // 2, 4, 8, 16, 32 GiB
 			while (held_bytes + sp > budget && sp > piece)
 				sp >>= 1;
 			hipMemGenericAllocationHandle_t hs;
 			if (hipMemCreate(&hs, sp, &prop, 0) == hipSuccess) {
-				held.push_back(hs);
+				held.push_back(HeldPiece{hs, sp});
 				held_bytes += sp;
 				if (fallback.size() >= slots_left)
 					searched_since_enough += sp;
@@ -415,10 +435,17 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 				(void)hipGetLastError();
 		}
 		hipMemGenericAllocationHandle_t hd;
-		hipError_t e = hipMemCreate(&hd, sz, &prop, 0);
-		if (e != hipSuccess && release_deferred()) {  // what earlier searches still hold may be what is missing
-			(void)hipGetLastError();
+		hipError_t e = hipSuccess;
+		if (pooled) {
+			hd = pool.back().h;
+			pool.pop_back();
+			held_bytes += sz;  // (booked like a fresh piece; taken off again below if it is kept)
+		} else {
 			e = hipMemCreate(&hd, sz, &prop, 0);
+			if (e != hipSuccess && release_deferred()) {  // what earlier searches still hold may be what is missing
+				(void)hipGetLastError();
+				e = hipMemCreate(&hd, sz, &prop, 0);
+			}
 		}
 		if (e != hipSuccess) {
 			if (trace)
@@ -428,7 +455,9 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 			break;
 		}
 		char *where = static_cast<char *>(va) + at;
-		const bool may_reject = held_bytes + sz <= budget && tries < max_tries && now_ms() - t_start < budget_ms;
+		if (pooled)
+			held_bytes -= sz;
+		const bool may_reject = (pooled || held_bytes + sz <= budget) && tries < max_tries && now_ms() - t_start < budget_ms;
 		int rel = 0;
 		if (may_reject) {
 			char *look = scratch + (tries++) * piece;
@@ -451,13 +480,16 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 		if (rel == 1 && sz == piece) {  // the musts only: keep it in reserve, look on
 			fallback.push_back(hd);
 			held_bytes += sz;
-			misses++;
+			if (!pooled)
+				misses++;
 			continue;
 		}
 		if (rel < 0) {
-			held.push_back(hd);
-			held_bytes += sz;
-			misses++;
+			held.push_back(HeldPiece{hd, sz});
+			if (!pooled) {  // (a pooled piece was allocated before this search began: not part of what IT holds back)
+				held_bytes += sz;
+				misses++;
+			}
 			turned++;
 			g_place_stats.rejected++;
 			if (fallback.size() >= slots_left)
@@ -478,6 +510,8 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 			unchecked++;
 			g_place_stats.gave_up++;
 		}
+		if (pooled)
+			from_pool++;
 		misses = 0;
 		(void)hipMemRelease(hd);  // the mapping keeps the memory
 		mapped.emplace_back(at, sz);
@@ -487,7 +521,9 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	{
 		std::lock_guard<std::mutex> lk(g_deferred_mu);
 		g_deferred_release.insert(g_deferred_release.end(), held.begin(), held.end());
-		g_deferred_release.insert(g_deferred_release.end(), fallback.begin(), fallback.end());
+		g_deferred_release.insert(g_deferred_release.end(), pool.begin(), pool.end());
+		for (auto hf : fallback)
+			g_deferred_release.push_back(HeldPiece{hf, piece});
 	}
 	if (sink)
 		(void)hipFree(sink);
@@ -501,9 +537,9 @@ static void *placed_alloc(size_t bytes, const PlaceHint &h, hipStream_t s)
 	trace_alloc(va, bytes);
 	if (trace)
 		std::fprintf(stderr, "[blasted_hip] placed %zu MiB at %p (%s %p): %zu pieces (%ld of them second best: the musts without the "
-		             "preference), %ld turned down, %ld kept unchecked, %zu MiB held back for the search, %.1f ms\n", total >> 20, va,
+		             "preference, %ld from what earlier searches had turned down), %ld turned down, %ld kept unchecked, %zu MiB held back for the search, %.1f ms\n", total >> 20, va,
 		             h.same ? "class of" : (h.prefer ? "preferably the class of" : "not the class of"), h.prefer ? h.prefer : ref,
-		             mapped.size(), second_best, turned, unchecked, held_bytes >> 20, now_ms() - t_start);
+		             mapped.size(), second_best, from_pool, turned, unchecked, held_bytes >> 20, now_ms() - t_start);
 	AllocRegistry &r = alloc_registry();
 	std::lock_guard<std::mutex> lk(r.mu);
 	AllocRegistry::Rec rec;
