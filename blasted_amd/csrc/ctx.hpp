@@ -251,9 +251,9 @@ struct Timing {
 void launch_read2_probe(const void *r0, const void *r1, long bytes_each, long piece_bytes, double *sink, hipStream_t s);  // probes build
 void launch_rw_probe(const void *rd, long rd_bytes, void *wr, long wr_bytes, double *sink, hipStream_t s, long passes = 1);  // kernels_aux.hip: address-class probe
 void launch_page_walk(const void *buf, long nloads, long stride_bytes, double *sink, hipStream_t s);  // probes build
-void trace_alloc(const void *p, size_t bytes);  // capi.hip
+void trace_alloc(const void *p, size_t bytes);  // devmem.hip
 
-// Device allocations of the library go through these two (capi.hip): same contract as hipMalloc / hipFree,
+// Device allocations of the library go through these two (devmem.hip): same contract as hipMalloc / hipFree,
 // plus per-operator accounting -- the bytes are booked on the operator whose entry point is running on this
 // thread (blasted_hip_memory_stats), or on nobody (raw buffers handed to the caller).
 hipError_t tracked_malloc(void **p, size_t bytes);
@@ -319,7 +319,7 @@ struct blasted_hip_prec_s {
 
 	long bytes_owned = 0, bytes_peak = 0;  // device memory this operator holds (tracked_malloc)
 
-	// class-aware placement (capi.hip, placed_alloc): what the next derived copy should avoid / share its address
+	// class-aware placement (devmem.hip, placed_alloc): what the next derived copy should avoid / share its address
 	// class with -- set by the entry point around the call that may allocate the copy
 	const void *place_avoid = nullptr, *place_same = nullptr;
 	size_t place_ref_bytes = 0;
