@@ -30,9 +30,16 @@ struct RGeo {
 	static constexpr int ROWBYTES = BS * 8;
 };
 
-template <int BS, int PART, int POST, int DSRC, int RCHUNK>
+// LS ("late store", round 4; what kernels_sweepw.hip has had since round 3 for column-major blocks): in-place bs = 4
+// triangular sweeps collect a workgroup's results in registers and store its 128 rows once, after the last step --
+// lane 2j + m of a row group keeps components (2m, 2m+1) of the row the group computed in step j (two lane permutes
+// per step), one 16-byte store per lane at the end instead of four 8-byte ones per step.  Other workgroups see a
+// chunk's rows up to three steps later: the more repeatable operator (see kernels_sweepw.hip for what that is worth
+// inside a flexible solver).  One row step in flight.
+template <int BS, int PART, int POST, int DSRC, int RCHUNK, bool LS = false>
 __global__ __launch_bounds__(256) void sweepwr_kernel(const SweepArgs a)
 {
+	static_assert(!LS || (BS == 4 && RCHUNK == 128 && (PART == PART_LOWER || PART == PART_UPPER)), "late store: bs 4 triangular sweeps");
 	using Ge = RGeo<BS>;
 	constexpr int HB = Ge::HB, G = Ge::G, RPW = Ge::RPW, RSTEP = Ge::RSTEP;
 	constexpr int CAP = 8 * RCHUNK;
@@ -67,6 +74,8 @@ __global__ __launch_bounds__(256) void sweepwr_kernel(const SweepArgs a)
 	const char *const dbase = reinterpret_cast<const char *>(a.dvals + (long)r0 * (BS * BS));
 	char *const obase = reinterpret_cast<char *>(a.xout + (long)r0 * BS);
 
+	rd2_t late;
+	late.x = late.y = 0.0;
 	for (int step = 0; step < RCHUNK / RSTEP; step++) {
 		const int ls = step * RSTEP + wave * RPW + g;
 		const bool ok = ls < rc;
@@ -151,8 +160,22 @@ __global__ __launch_bounds__(256) void sweepwr_kernel(const SweepArgs a)
 			if (a.b != 0.0)
 				out += a.b * rv;
 		}
-		if (ok && h == 0)
+		if (LS) {
+			// components (2m, 2m+1), m = q % 2, of this step's row: held by the lanes of rows 2m and 2m+1 of the group
+			const double v0 = __shfl(out, gbase + 4 * (q & 1), 64), v1 = __shfl(out, gbase + 4 * (q & 1) + 2, 64);
+			if ((q >> 1) == step) {
+				late.x = v0;
+				late.y = v1;
+			}
+		} else if (ok && h == 0)
 			*reinterpret_cast<double *>(obase + ((unsigned)lr * (unsigned)Ge::ROWBYTES + 8u * (unsigned)r)) = out;
+	}
+	if (LS) {
+		const int ls = (q >> 1) * RSTEP + wave * RPW + g;  // the row this lane's piece belongs to: step q / 2 of its group
+		if (ls < rc) {
+			const int lr = a.descending ? rc - 1 - ls : ls;
+			*reinterpret_cast<rd2_t *>(obase + ((unsigned)lr * (unsigned)Ge::ROWBYTES + 16u * (unsigned)(q & 1))) = late;
+		}
 	}
 }
 
@@ -166,7 +189,12 @@ void launch_r(const SweepArgs &a, hipStream_t s)
 {
 	constexpr int RCHUNK = 128;
 	const unsigned grid = (unsigned)(((long)a.pat.nbrows + RCHUNK - 1) / RCHUNK);
-	hipLaunchKernelGGL((sweepwr_kernel<BS, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a);
+	constexpr bool LSOK = BS == 4 && (PART == PART_LOWER || PART == PART_UPPER);
+	if (LSOK && a.latestore && !a.interleave && a.xin == a.xout &&
+	    (reinterpret_cast<uintptr_t>(a.xout) & 15u) == 0)
+		hipLaunchKernelGGL((sweepwr_kernel<BS, PART, POST, DSRC, RCHUNK, LSOK>), dim3(grid), dim3(256), 0, s, a);
+	else
+		hipLaunchKernelGGL((sweepwr_kernel<BS, PART, POST, DSRC, RCHUNK>), dim3(grid), dim3(256), 0, s, a);
 }
 
 template <int BS>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How much the asynchronous application differs from itself: two applications of s+s in-place sweeps to the same
 right-hand side, relative 2-norm of their difference, next to their distance from the exact solves -- per tuning.
-usage: async_noise.py [n=160] [bs=4] [tuning ...]"""
+usage: async_noise.py [n=160] [bs=4 | -4 for ROW-major blocks] [tuning ...]"""
 import sys
 
 import torch
@@ -13,12 +13,14 @@ from blasted_amd import capi, workloads as W  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 160
     bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    rowmajor = bs < 0
+    bs = abs(bs)
     dev = torch.device("cuda", 0)
     ms = W.poisson3d_device(n, 1, dev, grid="uniform")
     r_, c_ = torch.meshgrid(torch.arange(bs, device=dev), torch.arange(bs, device=dev), indexing="ij")
     Mb = torch.eye(bs, dtype=torch.float64, device=dev) * (1.0 + 0.1 * r_) + 0.03 * (((r_ + 2 * c_) % 3) - 1) * (r_ != c_)
     m = dict(ms)
-    m.update(bs=bs, vals=(ms["vals"][:, None] * Mb.t().reshape(-1)[None, :]).reshape(-1), rowmajor=False)
+    m.update(bs=bs, vals=(ms["vals"][:, None] * (Mb if rowmajor else Mb.t()).reshape(-1)[None, :]).reshape(-1), rowmajor=rowmajor)
     r = W.rhs_vector_device(m["nbrows"] * bs, dev)
     p = capi.Prec(0, torch.cuda.current_stream().cuda_stream)
     p.set_matrix(m)
