@@ -236,9 +236,15 @@ static double place_budget_ms(size_t bytes)
 // allocation after it take 6 s (profiles/r04_placement_ab_unbounded_bytes.txt).  The release is therefore put off to the
 // end of the entry point (release_deferred): the searches themselves no longer wait, whoever allocates next in the
 // process does, once.  Default (quick) search: at most 32 GiB and a quarter of what is free.
+static int g_quick_gib = [] {  // BLASTED_HIP_PLACEMENT_GIB: what the quick search may hold back (tools/probes/placement_ab.sh)
+	const char *e = std::getenv("BLASTED_HIP_PLACEMENT_GIB");
+	const int v = e ? std::atoi(e) : 32;
+	return v < 1 ? 1 : (v > 256 ? 256 : v);
+}();
+
 static size_t place_budget(size_t bytes)
 {
-	size_t want = g_placement >= 2 ? (size_t)256 << 30 : (size_t)32 << 30;
+	size_t want = g_placement >= 2 ? (size_t)256 << 30 : (size_t)g_quick_gib << 30;
 	// never more than what is free now, less the buffer itself and a reserve for everybody else on the device
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
