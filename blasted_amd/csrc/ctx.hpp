@@ -315,6 +315,12 @@ struct blasted_hip_prec_s {
 
 	bhip::Timing timing;
 
+	// thorough placement only ("placement=2"): a copy of the matrix values out of the class of the vector the asynchronous
+	// relaxation passes write (capi.hip, relax_impl) -- the borrowed values lie where the caller put them
+	double *relax_vals = nullptr;
+	bool relax_vals_valid = false;
+	long relax_passes = 0;  // passes since the matrix values last changed
+
 	double *zeros = nullptr;  // n zeros, never written: the iterate the first sweep of a small application reads (capi.hip)
 
 	long bytes_owned = 0, bytes_peak = 0;  // device memory this operator holds (tracked_malloc)

@@ -308,3 +308,46 @@ def test_class_aware_placement_changes_where_not_what():
         capi.set_tuning("placement=1")
         capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))
     assert torch.equal(results["0"], results["1"]) and torch.equal(results["0"], results["2"])
+
+
+def test_thorough_placement_keeps_its_own_matrix_copy_for_relaxation():
+    """Round 4, thorough placement only (`placement=2`): after a few asynchronous relaxation passes the operator
+    streams its OWN copy of the matrix values, kept out of the address class of the vector the passes write (the
+    borrowed values lie where the caller put them).  The copy changes where the pass reads, not what: the residual
+    history is the default's within the spread of asynchronous passes, the memory accounting shows the copy, and new
+    values (`set_values`) are followed."""
+    import torch
+    dev = torch.device("cuda:0")
+    m = W.poisson3d_device(128, 4, dev, grid="uniform")      # 1.9 GB of values
+    n = m["nbrows"] * 4
+    r = W.rhs_vector_device(n, dev)
+    res = {}
+    try:
+        for mode in ("0", "2"):
+            capi.set_tuning("placement=" + mode)
+            p = capi.Prec(0)
+            p.set_matrix(m)
+            p.jacobi_compute()
+            x = torch.zeros_like(r)
+            hist = []
+            for _ in range(6):
+                p.sgs_relax(r, x, 1, mode=capi.ASYNC)        # two passes per call
+                hist.append(float((r - p.spmv(x)).norm() / r.norm()))
+            res[mode] = hist
+            st = p.memory_stats()
+            assert st["derived_copies"] == (2 if mode == "2" else 0)
+            if mode == "2":
+                # new values: twice the matrix -- the relaxation must follow them (x <- the solution of 2 A x = r)
+                m2 = dict(m)
+                m2["vals"] = m["vals"] * 2.0
+                p.set_values(m2["vals"])
+                p.jacobi_compute()
+                x2 = torch.zeros_like(r)
+                for _ in range(6):
+                    p.sgs_relax(r, x2, 1, mode=capi.ASYNC)
+                assert float((2.0 * x2 - x).norm() / x.norm()) < 0.05
+            p.close()
+    finally:
+        capi.set_tuning("placement=1")
+    assert all(b < a for a, b in zip(res["2"], res["2"][1:]))
+    assert all(abs(a - b) < 0.02 * a for a, b in zip(res["0"], res["2"]))
