@@ -1535,6 +1535,12 @@ static int relax_impl(blasted_hip_prec p, const double *b, double *x, int maxits
 		// operator has done a few passes it keeps its own copy of the values out of x's class and streams that.
 		const size_t mbytes = sizeof(double) * (size_t)p->nvals();
 		if (g_placement >= 2 && mode == BLASTED_HIP_ASYNC && mbytes >= ((size_t)64 << 20)) {
+			if (!p->relax_vals_valid && !p->relax_vals && p->relax_passes >= 8) {
+				// only with room to spare: the copy is a convenience, never a reason for an application to fail
+				size_t free_b = 0, total_b = 0;
+				if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < mbytes + total_b / 8)
+					p->relax_passes = -(1L << 60);  // (not asked again for this operator)
+			}
 			if (!p->relax_vals_valid && p->relax_passes >= 8) {
 				if (!p->relax_vals) {
 					PlaceHint h;
