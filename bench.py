@@ -301,6 +301,7 @@ def product_default_block(m, r, z, cfg, s, dev_index, stream, capi, torch, ab):
     class-aware placement.  An operator of its own, built and dropped after the measured one's timed region."""
     capi.set_tuning("compactafter=-1")
     capi.set_tuning("placement=1")
+    capi.set_tuning("placeafter=%s" % os.environ.get("BLASTED_HIP_PLACE_AFTER", "256"))
     p0 = capi.Prec(dev_index, stream)
     p0.set_matrix(m)
     p0.ilu0_factorize(cfg["build"], init=capi.INIT_F_ORIGINAL, mode=capi.ASYNC)
@@ -321,6 +322,19 @@ def product_default_block(m, r, z, cfg, s, dev_index, stream, capi, torch, ab):
         switch_ms = timed(1)
         n_before += 1
         guard += 1
+    n_copy = n_before
+    placed0 = capi.placement_stats()["buffers"]
+    timed(3)
+    plain = timed(10)                                                        # plain compact copies
+    n_apps = n_copy + 3 + 10
+    # the default places the copies (quick search) once the operator has been applied 256 times in its life
+    place_ms, n_place, guard = None, None, 0
+    while capi.placement_stats()["buffers"] == placed0 and guard < 400:
+        place_ms = timed(1)
+        n_apps += 1
+        guard += 1
+    if capi.placement_stats()["buffers"] != placed0:
+        n_place = n_apps
     timed(3)
     p0.set_timing(True)
     p0.get_timing(reset=True)
@@ -333,14 +347,17 @@ def product_default_block(m, r, z, cfg, s, dev_index, stream, capi, torch, ab):
     p0.close()
     torch.cuda.synchronize()
     return {"in_place_apply_ms": in_place, "in_place_value": s / (in_place * 1e-3),
-            "copies_made_with_application": n_before, "that_application_ms": switch_ms,
+            "copies_made_with_application": n_copy, "that_application_ms": switch_ms,
+            "plain_copies_apply_ms": plain, "plain_copies_value": s / (plain * 1e-3),
+            "copies_placed_with_application": n_place, "placing_application_ms": place_ms if n_place else None,
             "steady_apply_ms": steady, "steady_value": s / (steady * 1e-3), "unit": "sweeps/s",
             "lower_ms": lo, "upper_ms": up, "upper_frac": ab["upper_sweep"] / (up * 1e-3) / 1e9 / HBM_PEAK_GBS if up > 0 else 0.0,
             "placement": "quick (default)", "where": where,
-            "note": "product defaults (BLASTED_HIP_COMPACT_AFTER / BLASTED_HIP_PLACEMENT unset): applications 2-11 read the "
-                    "factor in place; the application that makes the compact copies also pays the copy pass and the placement "
-                    "search; steady_* is the rate after it.  `value` of this line is the steady state of an operator whose "
-                    "copies were placed by the thorough search (config.placement)"}
+            "note": "product defaults (BLASTED_HIP_COMPACT_AFTER / BLASTED_HIP_PLACE_AFTER / BLASTED_HIP_PLACEMENT unset): "
+                    "applications 2-11 read the factor in place; the 17th makes plain compact copies (that_application_ms: the "
+                    "copy pass); once the operator has been applied 256 times in its life the quick placement search makes "
+                    "placed copies beside them (placing_application_ms); steady_* is the rate after that.  `value` of this "
+                    "line is the steady state of an operator whose copies were placed by the thorough search (config.placement)"}
 
 
 def fixed_upper_blocks(p, m, gen):
@@ -713,6 +730,7 @@ def main():
         # quick default search does not spend -- DESIGN.md, address classes)
         capi.set_tuning("compactafter=0")
         capi.set_tuning("placement=%s" % args.placement)
+        capi.set_tuning("placeafter=0")   # (the measured operator's copies are placed at once, by whichever search was asked for)
         p = capi.Prec(local_rank, stream)
         p.set_matrix(m)
         nb, nnzb, nnzl, nnzu = matrix_counts(m)
@@ -862,6 +880,7 @@ def main():
                 finally:  # back to this run's settings for what follows
                     capi.set_tuning("compactafter=0")
                     capi.set_tuning("placement=%s" % args.placement)
+                    capi.set_tuning("placeafter=0")
             if product_default is not None:
                 out["product_default"] = product_default
             if cache_resident:

@@ -229,6 +229,17 @@ static int g_level_store = [] {
 // (256^3: copies at once 40.1 / 187.3 ms at K = 1 / 16 against 34.0 / 189.8 without), 8 at the other block sizes
 // (unstructured bs = 5: even at K ~ 11), 4 for scalar rows (even at K ~ 5: in place a triangular sweep fetches whole
 // rows' lines for half their entries).
+// The quick placement search (the default) costs the application that runs it 105-145 ms at 256^3 bs=4 and returns
+// about 0.35 ms per application: it pays after a few hundred applications, the copy pass alone after twenty.  So the
+// default makes PLAIN copies when they pay (compactafter) and PLACED ones -- allocated beside the plain ones, which are
+// freed afterwards -- only once the operator has been applied `placeafter` times in its life (refactorisations keep the
+// count and the storage).  tuning "placeafter=N" / BLASTED_HIP_PLACE_AFTER; the thorough search ("placement=2") places
+// at once.
+static long g_place_after = [] {
+	const char *e = std::getenv("BLASTED_HIP_PLACE_AFTER");
+	return e ? std::atol(e) : 256L;
+}();
+
 static long g_compact_after = [] {
 	const char *e = std::getenv("BLASTED_HIP_COMPACT_AFTER");
 	return e ? std::atol(e) : -1L;
@@ -1156,14 +1167,29 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rscale = p->scaled ? p->scale : nullptr;
 		a.descending = 0;
 		const bool compact = g_compact && mode != BLASTED_HIP_LEVEL && napplysweeps > 0 && compact_now(p, p->fac_applies, p->fac_nat);
+		// (see g_place_after: the quick search waits until the operator has shown that it lives long enough to pay for it)
+		const bool want_placed = compact && g_placement && (g_placement >= 2 || p->ilu_apps_life >= g_place_after);
+		double *old_copies[4] = {nullptr, nullptr, nullptr, nullptr};
 		if (compact) {
+			p->ilu_apps_life++;
+			if (want_placed && !p->fac_placed && (p->fac_nat.l || p->fac_nat.u || p->fac_lvl.l || p->fac_lvl.u)) {
+				// plain copies exist: new, placed ones are made beside them (a release first would make the allocation wait for
+				// the driver's wipe), the old storage goes when both triangles have been copied
+				old_copies[0] = p->fac_nat.l;
+				old_copies[1] = p->fac_nat.u;
+				old_copies[2] = p->fac_lvl.l;
+				old_copies[3] = p->fac_lvl.u;
+				p->fac_nat = blasted_hip_prec_s::TriCopy();
+				p->fac_lvl = blasted_hip_prec_s::TriCopy();
+			}
 			// Musts (10 % each when they go wrong): the lower copy not in ytemp's class, the upper copy not in z's -- two of
 			// three classes will do, a search that holds back little finds them: the default.  Thorough ("placement=2") adds
 			// the preferences: ytemp moved out of r's and z's classes first (place_ytemp), then the lower copy preferably in
 			// r's class and the upper copy preferably in ytemp's; pieces that only meet the must are second best.
 			if (g_placement >= 2 && !p->fac_nat.l)
 				place_ytemp(p, dr, dz);
-			set_place_hint(p, p->ytemp, g_placement >= 2 ? dr : nullptr);
+			if (want_placed)
+				set_place_hint(p, p->ytemp, g_placement >= 2 ? dr : nullptr);
 			compact_args(p, false, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
 		}
@@ -1214,11 +1240,16 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		a.rhs = y;
 		a.descending = 1;
 		if (compact) {
-			set_place_hint(p, dz, g_placement >= 2 ? p->ytemp : nullptr);
+			if (want_placed)
+				set_place_hint(p, dz, g_placement >= 2 ? p->ytemp : nullptr);
 			const bool fresh = !p->fac_nat.u;
 			compact_args(p, true, a, p->iluvals, p->fac_nat);
 			set_place_hint(p, nullptr, nullptr);
-			if (fresh)
+			if (want_placed)
+				p->fac_placed = true;
+			for (double *o : old_copies)
+				dev_free(o);
+			if (fresh && want_placed)
 				report_classes(p, dr, dz);
 		}
 		const DSrc dsrc = scalar ? D_RECIP_DIAG : D_VALS_DIAG;
@@ -2025,6 +2056,8 @@ int blasted_hip_set_tuning(const char *spec)
 			g_compact = spec[8] != '0';
 		else if (spec && std::strncmp(spec, "compactafter=", 13) == 0)
 			g_compact_after = std::atol(spec + 13);
+		else if (spec && std::strncmp(spec, "placeafter=", 11) == 0)
+			g_place_after = std::atol(spec + 11);
 		else if (spec && std::strncmp(spec, "smallapply=", 11) == 0)
 			g_small_apply = spec[11] - '0';
 		else if (spec && std::strncmp(spec, "placement=", 10) == 0)

@@ -329,6 +329,8 @@ struct blasted_hip_prec_s {
 	// class with -- set by the entry point around the call that may allocate the copy
 	const void *place_avoid = nullptr, *place_same = nullptr;
 	size_t place_ref_bytes = 0;
+	bool fac_placed = false;    // the factor's compact copies lie in storage that a placement search chose
+	long ilu_apps_life = 0;     // asynchronous ILU applications since the pattern was set (refactorisations do not reset it)
 	bool ytemp_placed = false;  // ytemp has been checked against (and moved out of) the classes of a caller's r and z
 
 	long n() const { return (long)pat.nbrows * pat.bs; }

@@ -279,6 +279,7 @@ def test_class_aware_placement_changes_where_not_what():
     results = {}
     import os
     capi.set_tuning("compactafter=0")   # the copies with the first application, whatever the suite runs under
+    capi.set_tuning("placeafter=0")     # ... and the quick search with them (the default waits for the 256th application)
     try:
         for mode in ("0", "1", "2"):
             capi.set_tuning("placement=" + mode)
@@ -307,7 +308,52 @@ def test_class_aware_placement_changes_where_not_what():
     finally:
         capi.set_tuning("placement=1")
         capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))
+        capi.set_tuning("placeafter=" + os.environ.get("BLASTED_HIP_PLACE_AFTER", "256"))
     assert torch.equal(results["0"], results["1"]) and torch.equal(results["0"], results["2"])
+
+
+def test_quick_placement_waits_until_the_operator_has_lived_long_enough():
+    """The default's two stages: plain compact copies when they pay (here: at once), placed ones -- made beside the plain
+    ones, which are then freed -- once the operator has been applied `placeafter` times in its life, refactorisations
+    included.  Synchronous sweeps give the same bits before and after; the accounting returns to one copy's worth."""
+    import os
+    import torch
+    dev = torch.device("cuda:0")
+    m = W.poisson3d_device(128, 4, dev, grid="uniform")
+    n = m["nbrows"] * 4
+    r = W.rhs_vector_device(n, dev)
+    capi.set_tuning("compactafter=0")
+    capi.set_tuning("placeafter=6")
+    capi.set_tuning("placement=1")
+    try:
+        p = capi.Prec(0)
+        p.set_matrix(m)
+        p.ilu0_factorize(-1)
+        z = torch.zeros_like(r)
+        before = capi.placement_stats()
+        p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC, out=z)
+        first = z.clone()
+        assert capi.placement_stats()["buffers"] == before["buffers"]            # plain copies, no search
+        bytes_plain = p.memory_stats()["bytes"]
+        p.ilu0_apply(r, 3, mode=capi.ASYNC)
+        p.ilu0_factorize(-1)                                                     # a refactorisation keeps the count
+        for _ in range(3):
+            p.ilu0_apply(r, 3, mode=capi.ASYNC)
+        assert capi.placement_stats()["buffers"] == before["buffers"]            # applications 1 .. 5
+        for _ in range(3):
+            p.ilu0_apply(r, 3, mode=capi.ASYNC)                                  # ... the 7th places
+        after = capi.placement_stats()
+        assert after["buffers"] >= before["buffers"] + 2 and after["probes"] > before["probes"]
+        st = p.memory_stats()
+        assert st["derived_copies"] == 2 and abs(st["bytes"] - bytes_plain) < 64 << 20   # the plain copies are gone
+        p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC, out=z)
+        assert torch.equal(z, first)
+        where = p.placement_check(r, z)
+        assert where["lower_pieces"] == 1 and where["upper_pieces"] == 1
+        p.close()
+    finally:
+        capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))
+        capi.set_tuning("placeafter=" + os.environ.get("BLASTED_HIP_PLACE_AFTER", "256"))
 
 
 def test_thorough_placement_keeps_its_own_matrix_copy_for_relaxation():
