@@ -339,8 +339,12 @@ def test_quick_placement_waits_until_the_operator_has_lived_long_enough():
         p.ilu0_factorize(-1)                                                     # a refactorisation keeps the count
         for _ in range(3):
             p.ilu0_apply(r, 3, mode=capi.ASYNC)
+        p.ilu0_apply(r, 1, mode=capi.LEVEL)        # (the level ordering takes the plain copies' storage over: not counted)
         assert capi.placement_stats()["buffers"] == before["buffers"]            # applications 1 .. 5
-        for _ in range(3):
+        p.ilu0_apply(r, 3, mode=capi.ASYNC)                                      # the 6th: natural order again, still plain
+        assert capi.placement_stats()["buffers"] == before["buffers"]
+        bytes_plain = p.memory_stats()["bytes"]                                  # (with the level schedule and its iterates)
+        for _ in range(2):
             p.ilu0_apply(r, 3, mode=capi.ASYNC)                                  # ... the 7th places
         after = capi.placement_stats()
         assert after["buffers"] >= before["buffers"] + 2 and after["probes"] > before["probes"]
