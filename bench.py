@@ -323,17 +323,17 @@ def product_default_block(m, r, z, cfg, s, dev_index, stream, capi, torch, ab):
         n_before += 1
         guard += 1
     n_copy = n_before
-    placed0 = capi.placement_stats()["buffers"]
+    placed0 = capi.placement_stats()["probes"]   # (the placing application looks at the plain copies first and may keep them)
     timed(3)
     plain = timed(10)                                                        # plain compact copies
     n_apps = n_copy + 3 + 10
     # the default places the copies (quick search) once the operator has been applied 256 times in its life
     place_ms, n_place, guard = None, None, 0
-    while capi.placement_stats()["buffers"] == placed0 and guard < 400:
+    while capi.placement_stats()["probes"] == placed0 and guard < 400:
         place_ms = timed(1)
         n_apps += 1
         guard += 1
-    if capi.placement_stats()["buffers"] != placed0:
+    if capi.placement_stats()["probes"] != placed0:
         n_place = n_apps
     timed(3)
     p0.set_timing(True)

@@ -1173,14 +1173,47 @@ int blasted_hip_ilu0_apply(blasted_hip_prec p, const double *r, double *z, int n
 		if (compact) {
 			p->ilu_apps_life++;
 			if (want_placed && !p->fac_placed && (p->fac_nat.l || p->fac_nat.u || p->fac_lvl.l || p->fac_lvl.u)) {
-				// plain copies exist: new, placed ones are made beside them (a release first would make the allocation wait for
-				// the driver's wipe), the old storage goes when both triangles have been copied
-				old_copies[0] = p->fac_nat.l;
-				old_copies[1] = p->fac_nat.u;
-				old_copies[2] = p->fac_lvl.l;
-				old_copies[3] = p->fac_lvl.u;
-				p->fac_nat = blasted_hip_prec_s::TriCopy();
-				p->fac_lvl = blasted_hip_prec_s::TriCopy();
+				// plain copies exist.  The quick search first LOOKS at them: a triangle whose pieces all meet its must stays
+				// where it is (one process in three, the plain allocation happened to lie better than what a 32 GiB search
+				// then found).  For the others new, placed copies are made beside the old ones (a release first would make
+				// the allocation wait for the driver's wipe), the old storage goes when both triangles have been copied.
+				const size_t bs2b = sizeof(double) * (size_t)p->pat.bs * p->pat.bs;
+				const LevelSchedule &ns = p->natstore;
+				bool keep[2] = {false, false};
+				if (g_placement == 1 && ns.storage_built) {
+					double *sink = dev_alloc<double>(1);
+					for (int t = 0; t < 2; t++) {
+						double *buf = t ? (p->fac_nat.u ? p->fac_nat.u : p->fac_lvl.u) : (p->fac_nat.l ? p->fac_nat.l : p->fac_lvl.l);
+						const size_t bytes = (size_t)(t ? ns.nnz_dupper : ns.nnz_lower) * bs2b;
+						if (!buf || bytes < ((size_t)64 << 20))
+							continue;
+						PlaceHint h;
+						h.avoid = t ? static_cast<const void *>(dz) : static_cast<const void *>(p->ytemp);
+						h.ref_bytes = nbytes;
+						bool ok = true;
+						for (size_t at = 0; ok && at + ((size_t)64 << 20) <= bytes; at += (size_t)1 << 30) {
+							const size_t len = bytes - at < ((size_t)1 << 30) ? bytes - at : ((size_t)1 << 30);
+							ok = class_fits(reinterpret_cast<char *>(buf) + at, len, h, sink, p->stream) >= 0;
+						}
+						keep[t] = ok;
+						if (trace_placement())
+							std::fprintf(stderr, "[blasted_hip] the plain %s copy %s its must\n", t ? "upper" : "lower", ok ? "meets" : "does not meet");
+					}
+					BHIP_CHECK(hipStreamSynchronize(p->stream));
+					dev_free(sink);
+				}
+				if (!keep[0]) {
+					old_copies[0] = p->fac_nat.l;
+					old_copies[2] = p->fac_lvl.l;
+					p->fac_nat.l = p->fac_lvl.l = nullptr;
+					p->fac_nat.valid_l = p->fac_lvl.valid_l = false;
+				}
+				if (!keep[1]) {
+					old_copies[1] = p->fac_nat.u;
+					old_copies[3] = p->fac_lvl.u;
+					p->fac_nat.u = p->fac_lvl.u = nullptr;
+					p->fac_nat.valid_u = p->fac_lvl.valid_u = false;
+				}
 			}
 			// Musts (10 % each when they go wrong): the lower copy not in ytemp's class, the upper copy not in z's -- two of
 			// three classes will do, a search that holds back little finds them: the default.  Thorough ("placement=2") adds

@@ -347,13 +347,21 @@ def test_quick_placement_waits_until_the_operator_has_lived_long_enough():
         for _ in range(2):
             p.ilu0_apply(r, 3, mode=capi.ASYNC)                                  # ... the 7th places
         after = capi.placement_stats()
-        assert after["buffers"] >= before["buffers"] + 2 and after["probes"] > before["probes"]
+        # the 7th application looked at the plain copies (a triangle that meets its must stays where it is) and placed the
+        # others beside them
+        assert after["probes"] > before["probes"]
         st = p.memory_stats()
-        assert st["derived_copies"] == 2 and abs(st["bytes"] - bytes_plain) < 64 << 20   # the plain copies are gone
+        assert st["derived_copies"] == 2 and abs(st["bytes"] - bytes_plain) < 64 << 20   # replaced plain copies are gone
         p.ilu0_apply(r, 3, mode=capi.JACOBI_SYNC, out=z)
         assert torch.equal(z, first)
+        z2 = torch.zeros_like(r)
+        probes = capi.placement_stats()["probes"]
+        p.ilu0_apply(r, 3, mode=capi.ASYNC, out=z2)
+        assert capi.placement_stats()["probes"] == probes                        # ... once
         where = p.placement_check(r, z)
         assert where["lower_pieces"] == 1 and where["upper_pieces"] == 1
+        if after["unchecked"] == before["unchecked"]:
+            assert where["lower_in_ytemp_class"] == 0
         p.close()
     finally:
         capi.set_tuning("compactafter=" + os.environ.get("BLASTED_HIP_COMPACT_AFTER", "-1"))
